@@ -1,0 +1,184 @@
+/* hipfact — C ABI of the MI355X-native KKT linear-algebra backend for SLEQP.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain pointers and
+ * sizes (no torch types, no C++ types) and returns 0 on success or a negative
+ * HIPFACT_E* code; hipfact_last_error() gives the message.  The reference
+ * interface each entry point replaces is cited as (file:line) relative to
+ * chrhansk/sleqp v1.0.2 `src/main/`.
+ *
+ * The SLEQP-side binding (fact_hipfact.c: the five SleqpFactCallbacks plus
+ * sleqp_fact_create_default) is in shim/ and described in INTEGRATION.md.
+ */
+#ifndef HIPFACT_H
+#define HIPFACT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPFACT_VERSION "0.1.0"
+
+enum
+{
+  HIPFACT_OK         = 0,
+  HIPFACT_EINVAL     = -1, /* bad argument / malformed matrix              */
+  HIPFACT_EDEVICE    = -2, /* no usable HIP device, HIP runtime error       */
+  HIPFACT_ESINGULAR  = -3, /* zero / non-finite pivot (working set rank-deficient) */
+  HIPFACT_ENOMEM     = -4,
+  HIPFACT_ESTATE     = -5, /* call protocol violated (solve before set_matrix ...) */
+  HIPFACT_EINTERNAL  = -6
+};
+
+typedef struct hipfact_handle hipfact_handle;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Creates one backend instance bound to HIP device `device` (-1: read
+ * SLEQP_HIP_DEVICE, then LOCAL_RANK, else 0).  All device state (stream,
+ * buffers, symbolic cache) lives inside the handle; hipSetDevice is issued on
+ * every entry because the calling thread is arbitrary (thread_test.c:77-110).
+ * Fails with HIPFACT_EDEVICE when no GPU is present: there is no CPU fallback.
+ * Replaces: the `fact_data` constructors, e.g. ma57_data_create
+ * (fact/fact_ma57.c:733-807), lapack_data_create (fact/fact_lapack.c:36-50). */
+int hipfact_create(hipfact_handle** out, int device);
+
+/* Replaces SLEQP_FACT_FREE (fact/fact_types.h:23). Nulls *handle. */
+int hipfact_free(hipfact_handle** handle);
+
+/* Thread-local-free error text of the last failing call on this handle (or of
+ * hipfact_create when handle == NULL). */
+const char* hipfact_last_error(const hipfact_handle* handle);
+
+/* ---- SleqpFact callbacks ------------------------------------------------ */
+
+/* Replaces SLEQP_FACT_SET_MATRIX (fact/fact_types.h:9-10; dispatched from
+ * sleqp_fact_set_matrix, fact/fact.c:59-75).  K is the lower-triangular CSC
+ * matrix built by fill_aug_jac (aug_jac/standard_aug_jac.c:135-237) and read
+ * through sleqp_mat_num_cols / sleqp_mat_cols / sleqp_mat_rows / sleqp_mat_data
+ * (sparse/pub_mat.h:65-114): `colptr[N+1]`, `rowidx[nnz]` strictly ascending per
+ * column, `vals[nnz]`.  Host pointers; the arrays are copied/uploaded before the
+ * call returns (K is refilled in place by the caller afterwards,
+ * standard_aug_jac.c:143).  Symbolic analysis is cached and reused while the
+ * pattern is unchanged.  The numeric factorisation runs on the device. */
+int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* rowidx, const double* vals);
+
+/* Replaces SLEQP_FACT_SOLVE (fact/fact_types.h:12) for a sparse right-hand
+ * side given as the public SleqpVec fields (sparse/pub_vec.h:16-25): dimension
+ * `dim` (must equal N), `nnz` entries `indices[k]` ascending / `data[k]`.
+ * Equivalent to sleqp_vec_to_raw (sparse/vec.c:105-119) followed by the solve
+ * (fact_ma57.c:627-711, fact_lapack.c:125-154).  The solution stays on the
+ * device until hipfact_solution. */
+int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices, const double* data);
+
+/* Same with a dense host right-hand side of length N. */
+int hipfact_solve_dense(hipfact_handle* h, const double* rhs);
+
+/* Replaces SLEQP_FACT_SOLUTION (fact/fact_types.h:14-18): copies entries
+ * [begin, end) of the last solution into `out` (host, end-begin doubles).  The
+ * caller sparsifies with sleqp_vec_set_from_raw(sol, out, end-begin, zero_eps)
+ * exactly as every reference backend does (fact_ma57.c:713-730,
+ * fact_lapack.c:156-171).  May be called several times per solve with
+ * different ranges (standard_aug_jac.c:337-338 vs :382-386). */
+int hipfact_solution(hipfact_handle* h, double* out, int begin, int end);
+
+/* Replaces SLEQP_FACT_CONDITION (fact/fact_types.h:20-21; the callback may be
+ * NULL in the reference, fact.c:104-118).  Returns the pivot-ratio estimate
+ * max|d| / min|d| of the block-diagonal factor, like CHOLMOD's rcond-based
+ * value (fact_cholmod.c:197-209). */
+int hipfact_condition(hipfact_handle* h, double* condition);
+
+/* ---- device-resident variants (no PCIe in the hot loop) ----------------- */
+
+/* Numeric refactorisation with new values already in HBM (same pattern as the
+ * last hipfact_set_matrix).  `d_vals` is a device pointer to nnz doubles. */
+int hipfact_refactor_device(hipfact_handle* h, const double* d_vals);
+
+/* Solve with the right-hand side resident in HBM (`d_rhs`, N doubles) and
+ * write the solution to `d_sol` (N doubles, may alias d_rhs). */
+int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol);
+
+/* Device pointer to the last solution (N doubles, owned by the handle). */
+int hipfact_solution_device(hipfact_handle* h, const double** d_sol);
+
+/* Blocks until all work queued on the handle's stream has finished. */
+int hipfact_synchronize(hipfact_handle* h);
+
+/* The handle's HIP stream (hipStream_t as void*), for event timing. */
+int hipfact_stream(hipfact_handle* h, void** stream);
+
+/* ---- KKT assembly on the device ------------------------------------------ */
+
+/* Replaces reserve_aug_jac + fill_aug_jac (aug_jac/standard_aug_jac.c:106-237)
+ * for SLEQP_FACT_FLAGS_LOWER backends: builds the lower-triangular CSC K from
+ * the constraint Jacobian J (m_total x n, CSC: `j_colptr[n+1]`, `j_rowidx`,
+ * `j_vals`, host pointers) and the working-set index maps
+ * `var_index[n]` (sleqp_working_set_var_index, working_set.c:199-205; -1 = inactive)
+ * and `cons_index[m_total]` (sleqp_working_set_cons_index, working_set.c:191-197;
+ * already offset by the number of active variables, -1 = inactive).
+ * `working_set_size` = |W|.  The result stays on the device and becomes the
+ * matrix of the handle (as if hipfact_set_matrix had been called); its CSC
+ * arrays are bit-identical to what fill_aug_jac produces.  When out pointers
+ * are non-NULL the assembled arrays are also copied back (k_colptr: n+|W|+1
+ * ints; k_rowidx/k_vals: *k_nnz entries, capacity n + nnz(J) + #active vars). */
+int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_colptr, const int* j_rowidx,
+                         const double* j_vals, const int* var_index, const int* cons_index, int working_set_size,
+                         int* k_nnz, int* k_colptr, int* k_rowidx, double* k_vals);
+
+/* ---- sparse matrix-vector products ------------------------------------- */
+
+typedef struct hipfact_spmat hipfact_spmat;
+
+/* Uploads a CSC matrix (the SleqpMat layout, sparse/mat.c:11-25) once and
+ * keeps both orientations resident so that y = M x and y = M^T x are
+ * gather-only CSR kernels. */
+int hipfact_spmat_create(hipfact_handle* h, int num_rows, int num_cols, const int* colptr, const int* rowidx,
+                         const double* vals, hipfact_spmat** out);
+int hipfact_spmat_update_values(hipfact_spmat* M, const double* vals);
+int hipfact_spmat_free(hipfact_spmat** M);
+
+/* Replaces sleqp_mat_mult_vec (sparse/mat.c:282-310): y = M x, x dense host
+ * vector of length num_cols, y dense host vector of length num_rows. */
+int hipfact_spmat_mult_vec(hipfact_spmat* M, const double* x, double* y);
+/* Replaces sleqp_mat_mult_vec_trans (sparse/mat.c:312-363): y = M^T x dense;
+ * the caller applies the |y_j| > eps filter when packing the SleqpVec. */
+int hipfact_spmat_mult_vec_trans(hipfact_spmat* M, const double* x, double* y);
+/* Symmetric product from a lower-triangular CSC matrix, the explicit-Hessian
+ * precedent prod_from_hess_matrix (bindings/mex/mex_hess.c:85-139). */
+int hipfact_spmat_mult_vec_sym(hipfact_spmat* M, const double* x, double* y);
+/* Device-resident forms: trans = 0 (M x), 1 (M^T x), 2 (symmetric-from-lower). */
+int hipfact_spmat_mult_device(hipfact_spmat* M, int trans, const double* d_x, double* d_y);
+
+/* ---- options / introspection ------------------------------------------- */
+
+/* Options: "refine_steps" (iterative-refinement steps per solve, default 1),
+ * "ordering" (0 nested dissection, 1 AMD, 2 natural), "wmax", "nd_leaf",
+ * "force_generic", "use_graph", "pivot_tol". */
+int hipfact_set_option(hipfact_handle* h, const char* name, double value);
+
+/* Info: "N", "n", "m", "saddle", "nnzK", "nnzL", "nnzL_true", "flops",
+ * "flops_dense", "nsuper", "nlevels", "nprod", "L_bytes", "U_bytes",
+ * "analysis_s", "num_perturbed", "cache_hits", "max_r", "max_w",
+ * "solve_bytes", "factor_bytes", ... */
+int hipfact_get_info(const hipfact_handle* h, const char* name, double* value);
+
+/* ---- host-only symbolic plan (no GPU needed; used by the tests) ---------- */
+
+typedef struct hipfact_plan hipfact_plan;
+int hipfact_plan_create(int N, const int* colptr, const int* rowidx, const double* vals /* nullable */,
+                        hipfact_plan** out);
+void hipfact_plan_free(hipfact_plan** plan);
+const char* hipfact_plan_error(const hipfact_plan* plan);
+/* Exposes a named array of the plan (see sleqp_amd/csrc/plan.h); elem_size is
+ * 4 (int32) or 8 (int64). */
+int hipfact_plan_array(const hipfact_plan* plan, const char* name, const void** data, int64_t* len,
+                       int* elem_size);
+int hipfact_plan_scalar(const hipfact_plan* plan, const char* name, double* value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HIPFACT_H */

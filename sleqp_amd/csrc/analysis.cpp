@@ -1,0 +1,626 @@
+// Host-side symbolic analysis for the hipfact KKT backend: structure
+// detection, ordering, elimination tree, supernodes, multifrontal maps and the
+// level schedule.  Cached per sparsity pattern (the reference's backends redo
+// their analysis on every set_matrix: fact_ma57.c:529-625, fact_cholmod.c:133,
+// fact_umfpack.c:145-160).
+#include "plan.h"
+
+#include <algorithm>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "graph.h"
+
+namespace hipfact {
+
+namespace {
+
+double now_s() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+// Elimination tree of the matrix whose graph is g, eliminated in order perm
+// (Liu's algorithm with path compression).
+void etree(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm,
+           std::vector<int>& parent) {
+  const int m = g.n;
+  parent.assign(m, -1);
+  std::vector<int> anc(m, -1);
+  for (int k = 0; k < m; ++k) {
+    const int v = perm[k];
+    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+      int r = iperm[g.adj[q]];
+      if (r >= k) continue;
+      while (anc[r] != -1 && anc[r] != k) {
+        const int nx = anc[r];
+        anc[r] = k;
+        r = nx;
+      }
+      if (anc[r] == -1) {
+        anc[r] = k;
+        parent[r] = k;
+      }
+    }
+  }
+}
+
+// Postorder of a forest; children visited in ascending key order (so the child
+// with the largest key is numbered last, right before its parent).
+void postorder(const std::vector<int>& parent, const std::vector<int>* key, std::vector<int>& post) {
+  const int m = (int)parent.size();
+  std::vector<int> order(m);
+  std::iota(order.begin(), order.end(), 0);
+  if (key) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (*key)[a] > (*key)[b]; });
+  // build child lists by pushing in reverse visiting order
+  std::vector<int> head(m, -1), next(m, -1);
+  std::vector<int> roots;
+  if (!key) {
+    for (int k = m - 1; k >= 0; --k) {
+      if (parent[k] == -1)
+        roots.push_back(k);
+      else {
+        next[k] = head[parent[k]];
+        head[parent[k]] = k;
+      }
+    }
+    std::reverse(roots.begin(), roots.end());
+  } else {
+    // order is descending by key; pushing front yields ascending lists
+    for (int t = 0; t < m; ++t) {
+      const int k = order[t];
+      if (parent[k] == -1)
+        roots.push_back(k);
+      else {
+        next[k] = head[parent[k]];
+        head[parent[k]] = k;
+      }
+    }
+    std::reverse(roots.begin(), roots.end());
+  }
+  post.clear();
+  post.reserve(m);
+  std::vector<int> stack;
+  for (int r : roots) {
+    stack.push_back(r);
+    while (!stack.empty()) {
+      const int v = stack.back();
+      const int c = head[v];
+      if (c != -1) {
+        head[v] = next[c];
+        stack.push_back(c);
+      } else {
+        stack.pop_back();
+        post.push_back(v);
+      }
+    }
+  }
+  assert((int)post.size() == m);
+}
+
+struct RawSuper {
+  int c0 = 0, w = 0;
+  std::vector<int> rows;  // sorted, own columns first
+  int64_t zeros = 0;
+  bool dead = false;
+};
+
+// Supernodal symbolic factorisation for a postordered matrix.  Fills the
+// supernode partition with row structures and the per-column counts.
+void symbolic(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm,
+              const std::vector<int>& parent, std::vector<RawSuper>& sn, std::vector<int>& colcount) {
+  const int m = g.n;
+  sn.clear();
+  colcount.assign(m, 0);
+  std::vector<int> head(m, -1), next(m, -1);
+  for (int k = m - 1; k >= 0; --k)
+    if (parent[k] != -1) {
+      next[k] = head[parent[k]];
+      head[parent[k]] = k;
+    }
+  std::vector<int> mark(m, -1), sn_of(m, -1);
+  std::vector<int> extras;
+  for (int j = 0; j < m; ++j) {
+    const bool chain = (j > 0 && parent[j - 1] == j);
+    int stamp;
+    if (chain) {
+      stamp = sn.back().c0;  // rows of the open supernode are marked with its c0
+    } else {
+      stamp = j;
+    }
+    extras.clear();
+    auto visit = [&](int i) {
+      if (i > j && mark[i] != stamp) {
+        mark[i] = stamp;
+        extras.push_back(i);
+      }
+    };
+    const int v = perm[j];
+    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) visit(iperm[g.adj[q]]);
+    for (int c = head[j]; c != -1; c = next[c]) {
+      if (chain && c == j - 1) continue;
+      const RawSuper& cs = sn[sn_of[c]];
+      // c is the last column of its supernode: struct(c) = below rows
+      for (size_t t = cs.w; t < cs.rows.size(); ++t) visit(cs.rows[t]);
+    }
+    if (chain && extras.empty()) {
+      RawSuper& s = sn.back();
+      s.w += 1;
+      sn_of[j] = (int)sn.size() - 1;
+      colcount[j] = (int)s.rows.size() - (j - s.c0);
+      continue;
+    }
+    RawSuper ns;
+    ns.c0 = j;
+    ns.w = 1;
+    if (chain) {
+      // inherit the tail of the open supernode (it was marked with the old
+      // stamp; re-mark with the new one together with the extras)
+      const RawSuper& s = sn.back();
+      for (size_t t = (size_t)(j - s.c0) + 1; t < s.rows.size(); ++t) extras.push_back(s.rows[t]);
+    }
+    std::sort(extras.begin(), extras.end());
+    ns.rows.reserve(extras.size() + 1);
+    ns.rows.push_back(j);
+    ns.rows.insert(ns.rows.end(), extras.begin(), extras.end());
+    for (int i : ns.rows) mark[i] = j;  // stamp of the new open supernode = its c0
+    colcount[j] = (int)ns.rows.size();
+    sn_of[j] = (int)sn.size();
+    sn.push_back(std::move(ns));
+  }
+}
+
+inline int64_t trapezoid(int64_t w, int64_t r) { return w * r - w * (w - 1) / 2; }
+
+void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
+  const int ns = (int)sn.size();
+  if (ns == 0) return;
+  std::vector<int> col2sn(m);
+  for (int s = 0; s < ns; ++s)
+    for (int k = 0; k < sn[s].w; ++k) col2sn[sn[s].c0 + k] = s;
+  for (int s = 0; s + 1 < ns; ++s) {
+    RawSuper& a = sn[s];
+    if ((int)a.rows.size() == a.w) continue;  // root
+    const int p = col2sn[a.rows[a.w]];
+    if (p != s + 1) continue;
+    RawSuper& b = sn[p];
+    const int wm = a.w + b.w;
+    if (wm > prm.wmax) continue;
+    const int64_t ua = (int64_t)a.rows.size() - a.w;
+    const int64_t rb = (int64_t)b.rows.size();
+    const int64_t zeros = a.zeros + b.zeros + (int64_t)a.w * (rb - ua);
+    const int64_t tot = trapezoid(wm, a.w + rb);
+    const double frac = (double)zeros / (double)tot;
+    bool ok;
+    if (wm <= 4)
+      ok = true;
+    else if (wm <= 32)
+      ok = frac < prm.relax_small;
+    else if (wm <= 64)
+      ok = frac < prm.relax_mid;
+    else
+      ok = frac < prm.relax_big;
+    if (!ok) continue;
+    std::vector<int> rows;
+    rows.reserve(a.w + b.rows.size());
+    for (int k = 0; k < a.w; ++k) rows.push_back(a.c0 + k);
+    rows.insert(rows.end(), b.rows.begin(), b.rows.end());
+    b.rows.swap(rows);
+    b.c0 = a.c0;
+    b.w = wm;
+    b.zeros = zeros;
+    a.dead = true;
+    std::vector<int>().swap(a.rows);
+  }
+  std::vector<RawSuper> out;
+  out.reserve(ns);
+  for (auto& s : sn)
+    if (!s.dead) out.push_back(std::move(s));
+  sn.swap(out);
+}
+
+void split_wide(std::vector<RawSuper>& sn, int wmax) {
+  std::vector<RawSuper> out;
+  out.reserve(sn.size());
+  for (auto& s : sn) {
+    if (s.w <= wmax) {
+      out.push_back(std::move(s));
+      continue;
+    }
+    const int np = (s.w + wmax - 1) / wmax;
+    int done = 0;
+    for (int p = 0; p < np; ++p) {
+      const int wp = (s.w - done) / (np - p);
+      RawSuper t;
+      t.c0 = s.c0 + done;
+      t.w = wp;
+      t.rows.assign(s.rows.begin() + done, s.rows.end());
+      out.push_back(std::move(t));
+      done += wp;
+    }
+  }
+  sn.swap(out);
+}
+
+}  // namespace
+
+bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const PlanParams& prm_in, Plan& P) {
+  const double t0 = now_s();
+  PlanParams prm = prm_in;
+  if (const char* e = getenv("HIPFACT_ORDERING")) prm.ordering = atoi(e);
+  if (const char* e = getenv("HIPFACT_ND_LEAF")) prm.nd_leaf = atoi(e);
+  if (const char* e = getenv("HIPFACT_WMAX")) prm.wmax = atoi(e);
+  if (const char* e = getenv("HIPFACT_ND_SEP_FRAC")) prm.nd_sep_frac = atof(e);
+  if (const char* e = getenv("HIPFACT_RELAX")) {
+    double a, b, c;
+    if (sscanf(e, "%lf,%lf,%lf", &a, &b, &c) == 3) {
+      prm.relax_small = a;
+      prm.relax_mid = b;
+      prm.relax_big = c;
+    }
+  }
+  if (prm.wmax < 1) prm.wmax = 1;
+  if (prm.wmax > 128) prm.wmax = 128;
+
+  P = Plan();
+  P.N = N;
+  if (N < 0 || Kp == nullptr) {
+    P.error = "invalid matrix";
+    return false;
+  }
+  const int64_t nnz = N > 0 ? Kp[N] : 0;
+  P.nnzK = nnz;
+  // ---- validate: lower triangular, strictly ascending rows
+  for (int j = 0; j < N; ++j) {
+    if (Kp[j + 1] < Kp[j]) {
+      P.error = "column pointers not monotone";
+      return false;
+    }
+    for (int e = Kp[j]; e < Kp[j + 1]; ++e) {
+      if (Ki[e] < j || Ki[e] >= N) {
+        P.error = "matrix is not lower triangular (SLEQP_FACT_FLAGS_LOWER expected)";
+        return false;
+      }
+      if (e > Kp[j] && Ki[e] <= Ki[e - 1]) {
+        P.error = "row indices not strictly ascending";
+        return false;
+      }
+    }
+  }
+  P.Kp.assign(Kp, Kp + N + 1);
+  P.Ki.assign(Ki, Ki + nnz);
+
+  // ---- structure detection: K = [I A^T; A 0] with empty trailing columns
+  int n = N;
+  while (n > 0 && Kp[n] == Kp[n - 1]) --n;
+  bool saddle = !prm.force_generic;
+  if (n == 0 && N > 0) saddle = false;  // all-zero matrix
+  for (int j = 0; j < n && saddle; ++j) {
+    const int e0 = Kp[j];
+    if (Kp[j + 1] == e0 || Ki[e0] != j) saddle = false;
+    else if (Kx && Kx[e0] != 1.0) saddle = false;
+    else if (Kp[j + 1] > e0 + 1 && Ki[e0 + 1] < n) saddle = false;
+  }
+  P.saddle = saddle;
+  P.n = saddle ? n : 0;
+  P.m = saddle ? N - n : N;
+  const int m = P.m;
+  const int nx = P.n;
+
+  // ---- graph of M (saddle: S = A A^T, generic: K + K^T), no diagonal
+  Graph g;
+  g.n = m;
+  g.ptr.assign(m + 1, 0);
+  std::vector<int> ar_ptr, ar_col, ar_src;  // CSR of A in original row order
+  if (saddle) {
+    ar_ptr.assign(m + 1, 0);
+    for (int j = 0; j < nx; ++j)
+      for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) ++ar_ptr[Ki[e] - nx + 1];
+    for (int a = 0; a < m; ++a) ar_ptr[a + 1] += ar_ptr[a];
+    ar_col.resize(ar_ptr[m]);
+    ar_src.resize(ar_ptr[m]);
+    std::vector<int> fill(ar_ptr.begin(), ar_ptr.end() - 1);
+    for (int j = 0; j < nx; ++j)
+      for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+        const int a = Ki[e] - nx;
+        ar_col[fill[a]] = j;
+        ar_src[fill[a]] = e;
+        ++fill[a];
+      }
+    std::vector<int> mark(m, -1);
+    for (int a = 0; a < m; ++a) {
+      mark[a] = a;
+      for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
+        const int j = ar_col[q];
+        for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+          const int b = Ki[e] - nx;
+          if (mark[b] != a) {
+            mark[b] = a;
+            g.adj.push_back(b);
+          }
+        }
+      }
+      g.ptr[a + 1] = (int64_t)g.adj.size();
+    }
+  } else {
+    std::vector<int64_t> cnt(m + 1, 0);
+    for (int j = 0; j < N; ++j)
+      for (int e = Kp[j]; e < Kp[j + 1]; ++e)
+        if (Ki[e] != j) {
+          ++cnt[j + 1];
+          ++cnt[Ki[e] + 1];
+        }
+    for (int a = 0; a < m; ++a) cnt[a + 1] += cnt[a];
+    g.ptr.assign(cnt.begin(), cnt.end());
+    g.adj.resize(cnt[m]);
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    for (int j = 0; j < N; ++j)
+      for (int e = Kp[j]; e < Kp[j + 1]; ++e)
+        if (Ki[e] != j) {
+          g.adj[fill[j]++] = Ki[e];
+          g.adj[fill[Ki[e]]++] = j;
+        }
+  }
+
+  // ---- ordering
+  const double t1 = now_s();
+  std::vector<int> perm;
+  if (prm.ordering == 2) {
+    perm.resize(m);
+    std::iota(perm.begin(), perm.end(), 0);
+  } else if (prm.ordering == 1) {
+    amd_order(g, perm);
+  } else {
+    NDParams nd;
+    nd.max_sep_frac = prm.nd_sep_frac;
+    if (prm.nd_leaf > 0)
+      nd.leaf_size = prm.nd_leaf;
+    else
+      nd.leaf_size = 256;
+    nd_order(g, nd, perm);
+  }
+  std::vector<int> iperm(m);
+  for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
+  P.t_order = now_s() - t1;
+
+  // ---- elimination tree, postorder (twice: second time with children sorted
+  // by column count so that the heaviest child is adjacent to its parent)
+  const double t2 = now_s();
+  std::vector<int> parent, post, colcount;
+  std::vector<RawSuper> sn;
+  for (int pass = 0; pass < 2; ++pass) {
+    etree(g, perm, iperm, parent);
+    postorder(parent, pass == 0 ? nullptr : &colcount, post);
+    std::vector<int> perm2(m);
+    for (int k = 0; k < m; ++k) perm2[k] = perm[post[k]];
+    perm.swap(perm2);
+    for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
+    etree(g, perm, iperm, parent);
+    symbolic(g, perm, iperm, parent, sn, colcount);
+  }
+  P.nnzL_true = 0;
+  P.flops = 0;
+  for (int k = 0; k < m; ++k) {
+    P.nnzL_true += colcount[k];
+    P.flops += (double)colcount[k] * colcount[k];
+  }
+  amalgamate(sn, m, prm);
+  split_wide(sn, prm.wmax);
+
+  // ---- final supernode arrays
+  const int ns = (int)sn.size();
+  P.nsuper = ns;
+  P.perm = perm;
+  P.iperm = iperm;
+  P.sn_c0.resize(ns + 1);
+  P.sn_r.resize(ns);
+  P.sn_rowptr.assign(ns + 1, 0);
+  P.sn_parent.assign(ns, -1);
+  P.sn_level.assign(ns, 0);
+  P.sn_Loff.resize(ns);
+  P.sn_Uoff.resize(ns);
+  P.sn_uoff.resize(ns);
+  P.rel_ptr.assign(ns + 1, 0);
+  std::vector<int> col2sn(m);
+  for (int s = 0; s < ns; ++s) {
+    P.sn_c0[s] = sn[s].c0;
+    P.sn_r[s] = (int)sn[s].rows.size();
+    P.sn_rowptr[s + 1] = P.sn_rowptr[s] + P.sn_r[s];
+    for (int k = 0; k < sn[s].w; ++k) col2sn[sn[s].c0 + k] = s;
+  }
+  P.sn_c0[ns] = m;
+  P.sn_rows.resize(P.sn_rowptr[ns]);
+  int64_t Loff = 0, Uoff = 0, uoff = 0;
+  for (int s = 0; s < ns; ++s) {
+    std::copy(sn[s].rows.begin(), sn[s].rows.end(), P.sn_rows.begin() + P.sn_rowptr[s]);
+    const int w = sn[s].w, r = P.sn_r[s], u = r - w;
+    P.sn_Loff[s] = Loff;
+    P.sn_Uoff[s] = Uoff;
+    P.sn_uoff[s] = uoff;
+    // keep every panel / update matrix 16-byte aligned (even number of doubles)
+    Loff += ((int64_t)r * w + 1) & ~1LL;
+    Uoff += ((int64_t)u * u + 1) & ~1LL;
+    uoff += (u + 1) & ~1;
+    P.rel_ptr[s + 1] = P.rel_ptr[s] + u;
+    if (u > 0) P.sn_parent[s] = col2sn[sn[s].rows[w]];
+    P.nnzL += trapezoid(w, r);
+    for (int k = 0; k < w; ++k) P.flops_dense += (double)(r - k) * (r - k);
+    P.max_r = std::max(P.max_r, r);
+    P.max_w = std::max(P.max_w, w);
+    P.max_u = std::max(P.max_u, u);
+  }
+  P.L_size = Loff;
+  P.U_size = Uoff;
+  P.u_size = uoff;
+  // children, levels
+  P.child_ptr.assign(ns + 1, 0);
+  for (int s = 0; s < ns; ++s)
+    if (P.sn_parent[s] >= 0) ++P.child_ptr[P.sn_parent[s] + 1];
+  for (int s = 0; s < ns; ++s) P.child_ptr[s + 1] += P.child_ptr[s];
+  P.child_idx.resize(P.child_ptr[ns]);
+  {
+    std::vector<int> fill(P.child_ptr.begin(), P.child_ptr.end() - 1);
+    for (int s = 0; s < ns; ++s)
+      if (P.sn_parent[s] >= 0) P.child_idx[fill[P.sn_parent[s]]++] = s;
+  }
+  int nlev = 0;
+  for (int s = 0; s < ns; ++s) {  // children precede parents
+    const int p = P.sn_parent[s];
+    if (p >= 0) P.sn_level[p] = std::max(P.sn_level[p], P.sn_level[s] + 1);
+    nlev = std::max(nlev, P.sn_level[s] + 1);
+  }
+  P.nlevels = nlev;
+  P.level_ptr.assign(nlev + 1, 0);
+  for (int s = 0; s < ns; ++s) ++P.level_ptr[P.sn_level[s] + 1];
+  for (int l = 0; l < nlev; ++l) P.level_ptr[l + 1] += P.level_ptr[l];
+  P.level_sn.resize(ns);
+  {
+    std::vector<int> fill(P.level_ptr.begin(), P.level_ptr.end() - 1);
+    for (int s = 0; s < ns; ++s) P.level_sn[fill[P.sn_level[s]]++] = s;
+    // heaviest fronts first inside a level (better tail behaviour)
+    for (int l = 0; l < nlev; ++l)
+      std::stable_sort(P.level_sn.begin() + P.level_ptr[l], P.level_sn.begin() + P.level_ptr[l + 1],
+                       [&](int a, int b) {
+                         const double wa = (double)P.sn_r[a] * P.sn_r[a] * (P.sn_c0[a + 1] - P.sn_c0[a]);
+                         const double wb = (double)P.sn_r[b] * P.sn_r[b] * (P.sn_c0[b + 1] - P.sn_c0[b]);
+                         return wa > wb;
+                       });
+  }
+  // relative indices: position of each below-row in the parent's front
+  P.rel.resize(P.rel_ptr[ns]);
+  for (int s = 0; s < ns; ++s) {
+    const int p = P.sn_parent[s];
+    if (p < 0) continue;
+    const int w = sn[s].w;
+    const std::vector<int>& rs = sn[s].rows;
+    const std::vector<int>& rp = sn[p].rows;
+    size_t t = 0;
+    for (size_t q = w; q < rs.size(); ++q) {
+      while (t < rp.size() && rp[t] < rs[q]) ++t;
+      if (t == rp.size() || rp[t] != rs[q]) {
+        P.error = "internal: child structure not contained in parent";
+        return false;
+      }
+      P.rel[P.rel_ptr[s] + (q - w)] = (int)t;
+    }
+  }
+
+  // ---- M pattern in pivot order with target offsets into the L arena
+  P.Mp.assign(m + 1, 0);
+  for (int k = 0; k < m; ++k) {
+    const int v = perm[k];
+    int64_t c = 1;
+    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
+      if (iperm[g.adj[q]] > k) ++c;
+    P.Mp[k + 1] = P.Mp[k] + c;
+  }
+  P.Mi.resize(P.Mp[m]);
+  P.Mtarget.resize(P.Mp[m]);
+  {
+    std::vector<int> pos(m, -1);
+    for (int s = 0; s < ns; ++s) {
+      const std::vector<int>& rs = sn[s].rows;
+      const int r = (int)rs.size();
+      for (int t = 0; t < r; ++t) pos[rs[t]] = t;
+      for (int k = sn[s].c0; k < sn[s].c0 + sn[s].w; ++k) {
+        const int v = perm[k];
+        int64_t o = P.Mp[k];
+        P.Mi[o++] = k;
+        for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+          const int i = iperm[g.adj[q]];
+          if (i > k) P.Mi[o++] = i;
+        }
+        std::sort(P.Mi.begin() + P.Mp[k] + 1, P.Mi.begin() + P.Mp[k + 1]);
+        for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) {
+          const int t = pos[P.Mi[e]];
+          if (t < 0) {
+            P.error = "internal: matrix entry outside front";
+            return false;
+          }
+          P.Mtarget[e] = P.sn_Loff[s] + t + (int64_t)(k - sn[s].c0) * r;
+        }
+      }
+      for (int t = 0; t < r; ++t) pos[rs[t]] = -1;
+    }
+  }
+
+  // ---- value sources
+  if (saddle) {
+    // product lists: M(i,k) = sum_j A(perm[i], j) A(perm[k], j)
+    P.prod_ptr.assign(P.Mp[m] + 1, 0);
+    std::vector<int> pos(m, -1);
+    // pass 1: counts
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<int64_t> fill;
+      if (pass == 1) {
+        for (int64_t e = 0; e < P.Mp[m]; ++e) P.prod_ptr[e + 1] += P.prod_ptr[e];
+        P.nprod = P.prod_ptr[P.Mp[m]];
+        if (P.nprod > (int64_t)1 << 31) {
+          P.error = "product list too large (dense column in the constraint Jacobian?)";
+          return false;
+        }
+        P.prod_a.resize(P.nprod);
+        P.prod_b.resize(P.nprod);
+        fill.assign(P.prod_ptr.begin(), P.prod_ptr.end() - 1);
+      }
+      for (int k = 0; k < m; ++k) {
+        for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) pos[P.Mi[e]] = (int)(e - P.Mp[k]);
+        const int b = perm[k];
+        for (int q = ar_ptr[b]; q < ar_ptr[b + 1]; ++q) {
+          const int j = ar_col[q];
+          const int eb = ar_src[q];
+          for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+            const int i = iperm[Ki[e] - nx];
+            if (i < k) continue;
+            const int64_t me = P.Mp[k] + pos[i];
+            if (pass == 0)
+              ++P.prod_ptr[me + 1];
+            else {
+              P.prod_a[fill[me]] = e;
+              P.prod_b[fill[me]] = eb;
+              ++fill[me];
+            }
+          }
+        }
+      }
+    }
+    // SpMV structures
+    P.Ar_ptr.assign(m + 1, 0);
+    for (int k = 0; k < m; ++k) P.Ar_ptr[k + 1] = P.Ar_ptr[k] + (ar_ptr[perm[k] + 1] - ar_ptr[perm[k]]);
+    P.Ar_col.resize(P.Ar_ptr[m]);
+    P.Ar_src.resize(P.Ar_ptr[m]);
+    for (int k = 0; k < m; ++k) {
+      const int b = perm[k];
+      std::copy(ar_col.begin() + ar_ptr[b], ar_col.begin() + ar_ptr[b + 1], P.Ar_col.begin() + P.Ar_ptr[k]);
+      std::copy(ar_src.begin() + ar_ptr[b], ar_src.begin() + ar_ptr[b + 1], P.Ar_src.begin() + P.Ar_ptr[k]);
+    }
+    P.Kc_y.resize(nnz);
+    for (int j = 0; j < nx; ++j) {
+      P.Kc_y[Kp[j]] = -1;
+      for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) P.Kc_y[e] = iperm[Ki[e] - nx];
+    }
+  } else {
+    P.src.assign(P.Mp[m], -1);
+    for (int j = 0; j < N; ++j)
+      for (int e = Kp[j]; e < Kp[j + 1]; ++e) {
+        const int a = iperm[Ki[e]], b = iperm[j];
+        const int i = std::max(a, b), k = std::min(a, b);
+        auto first = P.Mi.begin() + P.Mp[k], last = P.Mi.begin() + P.Mp[k + 1];
+        auto it = (i == k) ? first : std::lower_bound(first + 1, last, i);
+        if (it == last || *it != i) {
+          P.error = "internal: K entry missing from M pattern";
+          return false;
+        }
+        P.src[it - P.Mi.begin()] = e;
+      }
+  }
+  P.t_symbolic = now_s() - t2;
+  P.t_total = now_s() - t0;
+  return true;
+}
+
+}  // namespace hipfact

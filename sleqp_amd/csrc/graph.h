@@ -1,0 +1,33 @@
+// Undirected graph in CSR form (no self loops, both directions stored).
+// Host-side analysis helper for the hipfact KKT backend.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hipfact {
+
+struct Graph {
+  int n = 0;
+  std::vector<int64_t> ptr;  // n+1
+  std::vector<int> adj;      // ptr[n]
+  int64_t nedges() const { return ptr.empty() ? 0 : ptr[n]; }
+};
+
+// Fill-reducing orderings.  perm[k] = vertex eliminated k-th.
+//
+// amd_order: quotient-graph approximate minimum degree (element absorption,
+// approximate external degrees, supervariable detection, mass elimination).
+void amd_order(const Graph& g, std::vector<int>& perm);
+
+struct NDParams {
+  int leaf_size = 200;        // stop dissecting below this many vertices
+  double max_sep_frac = 0.20; // reject separators larger than this fraction of the subgraph
+  double balance = 0.30;      // smaller side must hold at least this fraction
+};
+
+// nd_order: recursive level-structure nested dissection (separators last),
+// minimum degree on the leaves.  Exposes elimination-tree parallelism, which is
+// what the level-scheduled device factorisation needs.
+void nd_order(const Graph& g, const NDParams& p, std::vector<int>& perm);
+
+}  // namespace hipfact

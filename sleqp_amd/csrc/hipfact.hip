@@ -1,0 +1,890 @@
+// Host runtime and C ABI (include/hipfact.h) of the hipfact KKT backend.
+//
+// One handle = one backend instance = one HIP device + one stream, like one
+// SleqpFact object in the reference (fact/fact.c:21-45); no process-global
+// state.  All numerics run on the device; there is no CPU fallback: without a
+// usable GPU hipfact_create fails with HIPFACT_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hipfact.h"
+#include "device_types.h"
+#include "plan.h"
+
+// single translation unit: the kernels are compiled together with their launcher
+#include "kernels.hip"
+
+namespace hipfact {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+struct PinBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~PinBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+struct LevelInfo {
+  int begin = 0, count = 0;
+  size_t lds_factor = 0, lds_fwd = 0, lds_bwd = 0;
+};
+
+}  // namespace hipfact
+
+using namespace hipfact;
+
+static thread_local std::string g_create_error;
+
+struct hipfact_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  PlanParams prm;
+  Plan plan;
+  bool have_plan = false, factored = false, solved = false;
+  int refine_steps = 1;
+  long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
+  int info_host[INFO_WORDS] = {0, 0, 0, 0};
+  std::vector<LevelInfo> levels;
+  // plan on device
+  DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
+  DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
+  // numeric
+  DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val;
+  PinBuf h_stage, h_info;
+  // assembly
+  DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
+};
+
+struct hipfact_spmat {
+  hipfact_handle* h = nullptr;
+  int rows = 0, cols = 0;
+  long long nnz = 0;
+  DevBuf cp, ri, val;      // CSC as given (= CSR of M^T)
+  DevBuf tp, ti, tval, tsrc;  // CSR of M
+  DevBuf dx, dy;
+};
+
+#define HCHECK(h, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      (h)->error = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+      return e__ == hipErrorOutOfMemory ? HIPFACT_ENOMEM : HIPFACT_EDEVICE;                 \
+    }                                                                                       \
+  } while (0)
+
+static inline int nblocks(long long n, int cap = 4096) {
+  long long b = (n + FB - 1) / FB;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+template <class T>
+static int upload(hipfact_handle* h, DevBuf& buf, const std::vector<T>& v) {
+  HCHECK(h, buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
+  if (!v.empty()) HCHECK(h, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return HIPFACT_OK;
+}
+
+static int upload_plan(hipfact_handle* h) {
+  const Plan& P = h->plan;
+  const int ns = P.nsuper;
+  std::vector<SnDesc> sn(ns);
+  for (int s = 0; s < ns; ++s) {
+    SnDesc& d = sn[s];
+    d.Loff = P.sn_Loff[s];
+    d.Uoff = P.sn_Uoff[s];
+    d.uoff = P.sn_uoff[s];
+    d.rowoff = P.sn_rowptr[s];
+    d.reloff = P.rel_ptr[s];
+    d.c0 = P.sn_c0[s];
+    d.w = P.sn_c0[s + 1] - P.sn_c0[s];
+    d.r = P.sn_r[s];
+    d.parent = P.sn_parent[s];
+    d.child_begin = P.child_ptr[s];
+    d.child_end = P.child_ptr[s + 1];
+    d.pad0 = d.pad1 = 0;
+  }
+  int rc;
+  if ((rc = upload(h, h->d_sn, sn))) return rc;
+  if ((rc = upload(h, h->d_level_sn, P.level_sn))) return rc;
+  if ((rc = upload(h, h->d_rows, P.sn_rows))) return rc;
+  if ((rc = upload(h, h->d_rel, P.rel))) return rc;
+  if ((rc = upload(h, h->d_child, P.child_idx))) return rc;
+  if ((rc = upload(h, h->d_Mtarget, P.Mtarget))) return rc;
+  if ((rc = upload(h, h->d_perm, P.perm))) return rc;
+  if ((rc = upload(h, h->d_Kp, P.Kp))) return rc;
+  if ((rc = upload(h, h->d_Ki, P.Ki))) return rc;
+  if (P.saddle) {
+    if ((rc = upload(h, h->d_prod_ptr, P.prod_ptr))) return rc;
+    if ((rc = upload(h, h->d_prod_a, P.prod_a))) return rc;
+    if ((rc = upload(h, h->d_prod_b, P.prod_b))) return rc;
+    if ((rc = upload(h, h->d_Ar_ptr, P.Ar_ptr))) return rc;
+    if ((rc = upload(h, h->d_Ar_col, P.Ar_col))) return rc;
+    if ((rc = upload(h, h->d_Ar_src, P.Ar_src))) return rc;
+    if ((rc = upload(h, h->d_Kc_y, P.Kc_y))) return rc;
+    HCHECK(h, h->d_Ar_val.ensure(std::max<size_t>(P.Ar_src.size() * sizeof(double), 16)));
+  } else {
+    if ((rc = upload(h, h->d_src, P.src))) return rc;
+    // CSR of the lower triangle (row access for the symmetric residual)
+    const int N = P.N;
+    std::vector<int> Tp(N + 1, 0), Ti(P.nnzK), Tsrc(P.nnzK);
+    for (int j = 0; j < N; ++j)
+      for (int e = P.Kp[j]; e < P.Kp[j + 1]; ++e) ++Tp[P.Ki[e] + 1];
+    for (int i = 0; i < N; ++i) Tp[i + 1] += Tp[i];
+    std::vector<int> fill(Tp.begin(), Tp.end() - 1);
+    for (int j = 0; j < N; ++j)
+      for (int e = P.Kp[j]; e < P.Kp[j + 1]; ++e) {
+        const int q = fill[P.Ki[e]]++;
+        Ti[q] = j;
+        Tsrc[q] = e;
+      }
+    if ((rc = upload(h, h->d_Tp, Tp))) return rc;
+    if ((rc = upload(h, h->d_Ti, Ti))) return rc;
+    if ((rc = upload(h, h->d_Tsrc, Tsrc))) return rc;
+  }
+  // per-level launch metadata
+  h->levels.assign(P.nlevels, LevelInfo());
+  size_t max_lds = 0;
+  for (int l = 0; l < P.nlevels; ++l) {
+    LevelInfo& li = h->levels[l];
+    li.begin = P.level_ptr[l];
+    li.count = P.level_ptr[l + 1] - P.level_ptr[l];
+    int mw = 0, mr = 0, mu = 0;
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+      const int s = P.level_sn[q];
+      const int w = P.sn_c0[s + 1] - P.sn_c0[s], r = P.sn_r[s];
+      mw = std::max(mw, w);
+      mr = std::max(mr, r);
+      mu = std::max(mu, r - w);
+    }
+    const size_t wp = (size_t)((mw + 15) & ~15);
+    li.lds_factor = (wp * wp + wp + 2048) * sizeof(double);
+    li.lds_fwd = ((size_t)mr + mw + 2) * sizeof(double);
+    li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
+    max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
+  }
+  if (max_lds > 160 * 1024) {
+    h->error = "front too large for LDS-resident solve vectors";
+    return HIPFACT_EINTERNAL;
+  }
+  HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_factor_level),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_level),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // numeric workspaces
+  HCHECK(h, h->d_Kval.ensure(std::max<size_t>((size_t)P.nnzK * sizeof(double), 16)));
+  HCHECK(h, h->d_L.ensure(std::max<size_t>((size_t)P.L_size * sizeof(double), 16)));
+  HCHECK(h, h->d_U.ensure(std::max<size_t>((size_t)P.U_size * sizeof(double), 16)));
+  HCHECK(h, h->d_uvec.ensure(std::max<size_t>((size_t)P.u_size * sizeof(double), 16)));
+  HCHECK(h, h->d_y.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+  const size_t nb = std::max<size_t>((size_t)P.N * sizeof(double), 16);
+  HCHECK(h, h->d_rhs.ensure(nb));
+  HCHECK(h, h->d_sol.ensure(nb));
+  HCHECK(h, h->d_res.ensure(nb));
+  HCHECK(h, h->d_corr.ensure(nb));
+  HCHECK(h, h->d_info.ensure(INFO_WORDS * sizeof(int)));
+  HCHECK(h, h->d_minmax.ensure(2 * 64 * sizeof(double)));
+  HCHECK(h, h->h_info.ensure(INFO_WORDS * sizeof(int) + 2 * 64 * sizeof(double)));
+  return HIPFACT_OK;
+}
+
+// queue the numeric factorisation on the stream (values already in d_Kval)
+static int factor_async(hipfact_handle* h) {
+  const Plan& P = h->plan;
+  hipStream_t st = h->stream;
+  HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_WORDS * sizeof(int), st));
+  if (P.L_size > 0) HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double), st));
+  const long long nM = (long long)P.Mi.size();
+  if (nM > 0) {
+    if (P.saddle) {
+      hipLaunchKernelGGL(k_mvals_prod, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, st, nM,
+                         h->d_prod_ptr.as<long long>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
+                         h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+    } else {
+      hipLaunchKernelGGL(k_mvals_src, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, st, nM, h->d_src.as<int>(),
+                         h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+    }
+  }
+  if (P.saddle && !P.Ar_src.empty()) {
+    const long long na = (long long)P.Ar_src.size();
+    hipLaunchKernelGGL(k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, st, na, h->d_Ar_src.as<int>(),
+                       h->d_Kval.as<double>(), h->d_Ar_val.as<double>());
+  }
+  for (int l = 0; l < P.nlevels; ++l) {
+    const LevelInfo& li = h->levels[l];
+    hipLaunchKernelGGL(k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, st, h->d_sn.as<SnDesc>(),
+                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(),
+                       h->d_rel.as<int>(), h->d_child.as<int>(), h->d_info.as<int>());
+  }
+  HCHECK(h, hipGetLastError());
+  h->num_factor++;
+  h->factored = true;
+  h->solved = false;
+  return HIPFACT_OK;
+}
+
+static int check_info(hipfact_handle* h) {
+  HCHECK(h, hipMemcpyAsync(h->h_info.p, h->d_info.p, INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  memcpy(h->info_host, h->h_info.p, INFO_WORDS * sizeof(int));
+  if (h->info_host[INFO_ZERO_PIVOT] > 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "matrix is singular: %d zero or non-finite pivot(s)", h->info_host[INFO_ZERO_PIVOT]);
+    h->error = buf;
+    return HIPFACT_ESINGULAR;
+  }
+  return HIPFACT_OK;
+}
+
+// M y = t on the device (y in: t in pivot order, out: solution)
+static void solve_m_async(hipfact_handle* h) {
+  const Plan& P = h->plan;
+  hipStream_t st = h->stream;
+  for (int l = 0; l < P.nlevels; ++l) {
+    const LevelInfo& li = h->levels[l];
+    hipLaunchKernelGGL(k_fwd_level, dim3(li.count), dim3(FB), li.lds_fwd, st, h->d_sn.as<SnDesc>(),
+                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(),
+                       h->d_child.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>());
+  }
+  for (int l = P.nlevels - 1; l >= 0; --l) {
+    const LevelInfo& li = h->levels[l];
+    hipLaunchKernelGGL(k_bwd_level, dim3(li.count), dim3(FB), li.lds_bwd, st, h->d_sn.as<SnDesc>(),
+                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(),
+                       h->d_y.as<double>());
+  }
+}
+
+// z = K^-1 b without refinement; b, z device vectors of length N (may alias)
+static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
+  const Plan& P = h->plan;
+  hipStream_t st = h->stream;
+  if (P.N == 0) return;
+  if (P.saddle) {
+    if (P.m > 0) {
+      hipLaunchKernelGGL(k_rhs_saddle, dim3(nblocks(P.m)), dim3(FB), 0, st, P.m, P.n, h->d_Ar_ptr.as<int>(),
+                         h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b,
+                         h->d_y.as<double>());
+      solve_m_async(h);
+    }
+    hipLaunchKernelGGL(k_x_saddle, dim3(nblocks(P.N)), dim3(FB), 0, st, P.n, P.m, h->d_Kp.as<int>(),
+                       h->d_Kval.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), h->d_y.as<double>(), b, z);
+  } else {
+    hipLaunchKernelGGL(k_gather, dim3(nblocks(P.m)), dim3(FB), 0, st, (long long)P.m, h->d_perm.as<int>(), b,
+                       h->d_y.as<double>());
+    solve_m_async(h);
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, st, (long long)P.m, h->d_perm.as<int>(),
+                       h->d_y.as<double>(), z);
+  }
+}
+
+static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res) {
+  const Plan& P = h->plan;
+  hipStream_t st = h->stream;
+  if (P.saddle) {
+    hipLaunchKernelGGL(k_residual_saddle, dim3(nblocks(P.N)), dim3(FB), 0, st, P.n, P.m, h->d_Kp.as<int>(),
+                       h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
+                       h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res);
+  } else {
+    hipLaunchKernelGGL(k_residual_sym, dim3(nblocks(P.N)), dim3(FB), 0, st, P.N, h->d_Kp.as<int>(),
+                       h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(),
+                       h->d_Tsrc.as<int>(), b, z, res);
+  }
+}
+
+// full solve with iterative refinement: rhs in d_rhs, result in d_sol
+static int solve_async(hipfact_handle* h, const double* b, double* z) {
+  const Plan& P = h->plan;
+  if (P.N == 0) return HIPFACT_OK;
+  // b may alias z: keep a private copy of b when refining
+  const double* bb = b;
+  if (h->refine_steps > 0 && b == z) {
+    HCHECK(h, hipMemcpyAsync(h->d_rhs.p, b, (size_t)P.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    bb = h->d_rhs.as<double>();
+  }
+  solve_once_async(h, bb, z);
+  for (int it = 0; it < h->refine_steps; ++it) {
+    residual_async(h, bb, z, h->d_res.as<double>());
+    solve_once_async(h, h->d_res.as<double>(), h->d_corr.as<double>());
+    hipLaunchKernelGGL(k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, h->stream, (long long)P.N, 1.0,
+                       h->d_corr.as<double>(), z);
+  }
+  HCHECK(h, hipGetLastError());
+  h->num_solve++;
+  h->solved = true;
+  return HIPFACT_OK;
+}
+
+static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* rowidx, const double* vals) {
+  const long long nnz = N > 0 ? colptr[N] : 0;
+  if (h->have_plan && h->plan.N == N && h->plan.nnzK == nnz &&
+      memcmp(h->plan.Kp.data(), colptr, (size_t)(N + 1) * sizeof(int)) == 0 &&
+      (nnz == 0 || memcmp(h->plan.Ki.data(), rowidx, (size_t)nnz * sizeof(int)) == 0)) {
+    // pattern unchanged.  The saddle classification also depends on the unit
+    // diagonal values; re-check them (n entries)
+    bool ok = true;
+    if (h->plan.saddle && vals)
+      for (int j = 0; j < h->plan.n && ok; ++j) ok = (vals[colptr[j]] == 1.0);
+    if (ok) {
+      h->cache_hits++;
+      return HIPFACT_OK;
+    }
+  }
+  h->have_plan = false;
+  h->factored = false;
+  try {
+    if (!build_plan(N, colptr, rowidx, vals, h->prm, h->plan)) {
+      h->error = h->plan.error;
+      return HIPFACT_EINVAL;
+    }
+  } catch (const std::bad_alloc&) {
+    h->error = "out of host memory during analysis";
+    return HIPFACT_ENOMEM;
+  }
+  h->analyses++;
+  int rc = upload_plan(h);
+  if (rc) return rc;
+  h->have_plan = true;
+  return HIPFACT_OK;
+}
+
+static int enter(hipfact_handle* h) {
+  if (!h) return HIPFACT_EINVAL;
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) {
+    h->error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return HIPFACT_EDEVICE;
+  }
+  return HIPFACT_OK;
+}
+
+template <int LANES>
+static void launch_spmv(hipStream_t st, int nrows, const int* ptr, const int* idx, const double* val, const int* ptr2,
+                        const int* idx2, const double* val2, const double* x, double* y) {
+  const int rows_per_block = FB / LANES;
+  long long blocks = ((long long)nrows + rows_per_block - 1) / rows_per_block;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_spmv_csr<LANES>, dim3((int)blocks), dim3(FB), 0, st, nrows, ptr, idx, val, ptr2, idx2, val2,
+                     x, y);
+}
+
+extern "C" {
+
+int hipfact_create(hipfact_handle** out, int device) {
+  if (!out) return HIPFACT_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                     "); hipfact has no CPU fallback";
+    return HIPFACT_EDEVICE;
+  }
+  if (device < 0) {
+    const char* s = getenv("SLEQP_HIP_DEVICE");
+    if (!s) s = getenv("LOCAL_RANK");
+    device = s ? atoi(s) : 0;
+    if (device < 0 || device >= count) device = device % count;
+  }
+  if (device >= count) {
+    g_create_error = "device ordinal out of range";
+    return HIPFACT_EDEVICE;
+  }
+  hipfact_handle* h = new (std::nothrow) hipfact_handle();
+  if (!h) return HIPFACT_ENOMEM;
+  h->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("device init: ") + hipGetErrorString(e);
+    delete h;
+    return HIPFACT_EDEVICE;
+  }
+  if (const char* s = getenv("HIPFACT_REFINE")) h->refine_steps = atoi(s);
+  *out = h;
+  return HIPFACT_OK;
+}
+
+int hipfact_free(hipfact_handle** handle) {
+  if (!handle || !*handle) return HIPFACT_OK;
+  hipfact_handle* h = *handle;
+  (void)hipSetDevice(h->device);
+  if (h->stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  *handle = nullptr;
+  return HIPFACT_OK;
+}
+
+const char* hipfact_last_error(const hipfact_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* rowidx, const double* vals) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (N < 0 || !colptr || (N > 0 && colptr[N] > 0 && (!rowidx || !vals))) {
+    h->error = "hipfact_set_matrix: invalid arguments";
+    return HIPFACT_EINVAL;
+  }
+  if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) return rc;
+  const size_t nnz = (size_t)h->plan.nnzK;
+  if (nnz > 0) {
+    HCHECK(h, h->h_stage.ensure(nnz * sizeof(double)));
+    memcpy(h->h_stage.p, vals, nnz * sizeof(double));
+    HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->h_stage.p, nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  if ((rc = factor_async(h))) return rc;
+  return check_info(h);
+}
+
+int hipfact_refactor_device(hipfact_handle* h, const double* d_vals) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!h->have_plan) {
+    h->error = "hipfact_refactor_device: no matrix pattern set";
+    return HIPFACT_ESTATE;
+  }
+  if (d_vals && d_vals != h->d_Kval.p && h->plan.nnzK > 0)
+    HCHECK(h, hipMemcpyAsync(h->d_Kval.p, d_vals, (size_t)h->plan.nnzK * sizeof(double), hipMemcpyDeviceToDevice,
+                             h->stream));
+  return factor_async(h);
+}
+
+static int require_factor(hipfact_handle* h, const char* who) {
+  if (!h->have_plan || !h->factored) {
+    h->error = std::string(who) + ": no factorisation (call hipfact_set_matrix first)";
+    return HIPFACT_ESTATE;
+  }
+  return HIPFACT_OK;
+}
+
+int hipfact_solve_dense(hipfact_handle* h, const double* rhs) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if ((rc = require_factor(h, "hipfact_solve_dense"))) return rc;
+  const size_t N = (size_t)h->plan.N;
+  if (N == 0) return HIPFACT_OK;
+  if (!rhs) return HIPFACT_EINVAL;
+  HCHECK(h, h->h_stage.ensure(N * sizeof(double)));
+  HCHECK(h, hipStreamSynchronize(h->stream));  // staging buffer may still be in flight
+  memcpy(h->h_stage.p, rhs, N * sizeof(double));
+  HCHECK(h, hipMemcpyAsync(h->d_rhs.p, h->h_stage.p, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
+}
+
+int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices, const double* data) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if ((rc = require_factor(h, "hipfact_solve_sparse"))) return rc;
+  const int N = h->plan.N;
+  if (dim != N || nnz < 0 || nnz > N || (nnz > 0 && (!indices || !data))) {
+    h->error = "hipfact_solve_sparse: rhs dimension does not match the matrix";
+    return HIPFACT_EINVAL;
+  }
+  if (N == 0) return HIPFACT_OK;
+  for (int k = 0; k < nnz; ++k)
+    if (indices[k] < 0 || indices[k] >= N) {
+      h->error = "hipfact_solve_sparse: index out of range";
+      return HIPFACT_EINVAL;
+    }
+  HCHECK(h, hipMemsetAsync(h->d_rhs.p, 0, (size_t)N * sizeof(double), h->stream));
+  if (nnz > 0) {
+    const size_t bytes = (size_t)nnz * (sizeof(double) + sizeof(int));
+    HCHECK(h, h->h_stage.ensure(bytes));
+    HCHECK(h, h->d_sp_val.ensure((size_t)nnz * sizeof(double)));
+    HCHECK(h, h->d_sp_idx.ensure((size_t)nnz * sizeof(int)));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    double* sv = h->h_stage.as<double>();
+    int* si = reinterpret_cast<int*>(sv + nnz);
+    memcpy(sv, data, (size_t)nnz * sizeof(double));
+    memcpy(si, indices, (size_t)nnz * sizeof(int));
+    HCHECK(h, hipMemcpyAsync(h->d_sp_val.p, sv, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->d_sp_idx.p, si, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_scatter_sparse, dim3(nblocks(nnz)), dim3(FB), 0, h->stream, nnz, h->d_sp_idx.as<int>(),
+                       h->d_sp_val.as<double>(), h->d_rhs.as<double>());
+  }
+  return solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
+}
+
+int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if ((rc = require_factor(h, "hipfact_solve_device"))) return rc;
+  if (h->plan.N > 0 && (!d_rhs || !d_sol)) return HIPFACT_EINVAL;
+  return solve_async(h, d_rhs, d_sol);
+}
+
+int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!h->solved && h->plan.N > 0) {
+    h->error = "hipfact_solution: no solve has been performed";
+    return HIPFACT_ESTATE;
+  }
+  if (begin < 0 || end < begin || end > h->plan.N || (end > begin && !out)) {
+    h->error = "hipfact_solution: range outside [0, N]";
+    return HIPFACT_EINVAL;
+  }
+  const size_t cnt = (size_t)(end - begin);
+  if (cnt == 0) return HIPFACT_OK;
+  HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
+  HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  memcpy(out, h->h_stage.p, cnt * sizeof(double));
+  return HIPFACT_OK;
+}
+
+int hipfact_solution_device(hipfact_handle* h, const double** d_sol) {
+  if (!h || !d_sol) return HIPFACT_EINVAL;
+  *d_sol = h->d_sol.as<double>();
+  return HIPFACT_OK;
+}
+
+int hipfact_condition(hipfact_handle* h, double* condition) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if ((rc = require_factor(h, "hipfact_condition"))) return rc;
+  if (!condition) return HIPFACT_EINVAL;
+  const Plan& P = h->plan;
+  if (P.nsuper == 0) {
+    *condition = 1.0;
+    return HIPFACT_OK;
+  }
+  hipLaunchKernelGGL(k_pivot_minmax, dim3(64), dim3(FB), 0, h->stream, P.nsuper, h->d_sn.as<SnDesc>(),
+                     h->d_L.as<double>(), h->d_minmax.as<double>());
+  double* hm = reinterpret_cast<double*>(h->h_info.as<char>() + INFO_WORDS * sizeof(int));
+  HCHECK(h, hipMemcpyAsync(hm, h->d_minmax.p, 2 * 64 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  double lo = 1.7e308, hi = 0.0;
+  for (int b = 0; b < 64; ++b) {
+    lo = std::min(lo, hm[2 * b]);
+    hi = std::max(hi, hm[2 * b + 1]);
+  }
+  if (P.saddle) {  // the leaf pivots of the identity block are 1
+    lo = std::min(lo, 1.0);
+    hi = std::max(hi, 1.0);
+  }
+  *condition = (lo > 0.0) ? hi / lo : INFINITY;
+  return HIPFACT_OK;
+}
+
+int hipfact_synchronize(hipfact_handle* h) {
+  int rc = enter(h);
+  if (rc) return rc;
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  return HIPFACT_OK;
+}
+
+int hipfact_stream(hipfact_handle* h, void** stream) {
+  if (!h || !stream) return HIPFACT_EINVAL;
+  *stream = (void*)h->stream;
+  return HIPFACT_OK;
+}
+
+// ---------------------------------------------------------------------------
+int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_colptr, const int* j_rowidx,
+                         const double* j_vals, const int* var_index, const int* cons_index, int working_set_size,
+                         int* k_nnz, int* k_colptr, int* k_rowidx, double* k_vals) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (n < 0 || m_total < 0 || working_set_size < 0 || !j_colptr || !var_index || (m_total > 0 && !cons_index)) {
+    h->error = "hipfact_assemble_kkt: invalid arguments";
+    return HIPFACT_EINVAL;
+  }
+  const int jnnz = n > 0 ? j_colptr[n] : 0;
+  const int N = n + working_set_size;
+  int nav = 0;
+  for (int j = 0; j < n; ++j) nav += (var_index[j] >= 0);
+  const size_t cap = (size_t)n + jnnz + nav;  // reserve_aug_jac (standard_aug_jac.c:106-133)
+  hipStream_t st = h->stream;
+  HCHECK(h, h->d_jp.ensure((size_t)(n + 1) * sizeof(int)));
+  HCHECK(h, h->d_ji.ensure(std::max<size_t>((size_t)jnnz * sizeof(int), 16)));
+  HCHECK(h, h->d_jx.ensure(std::max<size_t>((size_t)jnnz * sizeof(double), 16)));
+  HCHECK(h, h->d_vi.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
+  HCHECK(h, h->d_ci.ensure(std::max<size_t>((size_t)m_total * sizeof(int), 16)));
+  HCHECK(h, h->d_cnt.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
+  HCHECK(h, h->d_akp.ensure((size_t)(N + 1) * sizeof(int)));
+  HCHECK(h, h->d_aki.ensure(std::max<size_t>(cap * sizeof(int), 16)));
+  HCHECK(h, h->d_akx.ensure(std::max<size_t>(cap * sizeof(double), 16)));
+  HCHECK(h, hipMemcpyAsync(h->d_jp.p, j_colptr, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  if (jnnz > 0) {
+    HCHECK(h, hipMemcpyAsync(h->d_ji.p, j_rowidx, (size_t)jnnz * sizeof(int), hipMemcpyHostToDevice, st));
+    HCHECK(h, hipMemcpyAsync(h->d_jx.p, j_vals, (size_t)jnnz * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  if (n > 0) HCHECK(h, hipMemcpyAsync(h->d_vi.p, var_index, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+  if (m_total > 0)
+    HCHECK(h, hipMemcpyAsync(h->d_ci.p, cons_index, (size_t)m_total * sizeof(int), hipMemcpyHostToDevice, st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_asm_count, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
+                       h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_cnt.as<int>());
+  hipLaunchKernelGGL(k_asm_scan, dim3(1), dim3(1024), 0, st, n, N, h->d_cnt.as<int>(), h->d_akp.as<int>());
+  if (n > 0)
+    hipLaunchKernelGGL(k_asm_fill, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
+                       h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_akp.as<int>(),
+                       h->d_aki.as<int>(), h->d_akx.as<double>());
+  HCHECK(h, hipGetLastError());
+  // the pattern is needed on the host for the (cached) symbolic analysis
+  std::vector<int> kp(N + 1);
+  HCHECK(h, hipMemcpyAsync(kp.data(), h->d_akp.p, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  HCHECK(h, hipStreamSynchronize(st));
+  const int nnz = kp[N];
+  if ((size_t)nnz > cap) {
+    h->error = "hipfact_assemble_kkt: internal count mismatch";
+    return HIPFACT_EINTERNAL;
+  }
+  std::vector<int> ki(nnz);
+  if (nnz > 0) HCHECK(h, hipMemcpy(ki.data(), h->d_aki.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
+  if (k_nnz) *k_nnz = nnz;
+  if (k_colptr) memcpy(k_colptr, kp.data(), (size_t)(N + 1) * sizeof(int));
+  if (k_rowidx && nnz > 0) memcpy(k_rowidx, ki.data(), (size_t)nnz * sizeof(int));
+  if (k_vals && nnz > 0) HCHECK(h, hipMemcpy(k_vals, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+  // values of the unit diagonal are 1 by construction: pattern-only analysis
+  if ((rc = ensure_plan(h, N, kp.data(), ki.data(), nullptr))) return rc;
+  if (nnz > 0)
+    HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if ((rc = factor_async(h))) return rc;
+  return check_info(h);
+}
+
+// ---------------------------------------------------------------------------
+int hipfact_spmat_create(hipfact_handle* h, int num_rows, int num_cols, const int* colptr, const int* rowidx,
+                         const double* vals, hipfact_spmat** out) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!out || num_rows < 0 || num_cols < 0 || !colptr) return HIPFACT_EINVAL;
+  *out = nullptr;
+  const long long nnz = num_cols > 0 ? colptr[num_cols] : 0;
+  for (int j = 0; j < num_cols; ++j)
+    for (int e = colptr[j]; e < colptr[j + 1]; ++e)
+      if (rowidx[e] < 0 || rowidx[e] >= num_rows) {
+        h->error = "hipfact_spmat_create: row index out of range";
+        return HIPFACT_EINVAL;
+      }
+  hipfact_spmat* M = new (std::nothrow) hipfact_spmat();
+  if (!M) return HIPFACT_ENOMEM;
+  M->h = h;
+  M->rows = num_rows;
+  M->cols = num_cols;
+  M->nnz = nnz;
+  std::vector<int> tp(num_rows + 1, 0), ti(nnz), tsrc(nnz);
+  for (long long e = 0; e < nnz; ++e) ++tp[rowidx[e] + 1];
+  for (int i = 0; i < num_rows; ++i) tp[i + 1] += tp[i];
+  {
+    std::vector<int> fill(tp.begin(), tp.end() - 1);
+    for (int j = 0; j < num_cols; ++j)
+      for (int e = colptr[j]; e < colptr[j + 1]; ++e) {
+        const int q = fill[rowidx[e]]++;
+        ti[q] = j;
+        tsrc[q] = e;
+      }
+  }
+  auto fail = [&](int code) {
+    delete M;
+    return code;
+  };
+  hipStream_t st = h->stream;
+#define SP_UP(buf, ptr, bytes)                                                                              \
+  do {                                                                                                      \
+    if (M->buf.ensure(std::max<size_t>((bytes), 16)) != hipSuccess) {                                       \
+      h->error = "hipfact_spmat_create: out of device memory";                                              \
+      return fail(HIPFACT_ENOMEM);                                                                          \
+    }                                                                                                       \
+    if ((bytes) > 0 && hipMemcpyAsync(M->buf.p, (ptr), (bytes), hipMemcpyHostToDevice, st) != hipSuccess) { \
+      h->error = "hipfact_spmat_create: upload failed";                                                     \
+      return fail(HIPFACT_EDEVICE);                                                                         \
+    }                                                                                                       \
+  } while (0)
+  SP_UP(cp, colptr, (size_t)(num_cols + 1) * sizeof(int));
+  SP_UP(ri, rowidx, (size_t)nnz * sizeof(int));
+  SP_UP(val, vals, (size_t)nnz * sizeof(double));
+  SP_UP(tp, tp.data(), (size_t)(num_rows + 1) * sizeof(int));
+  SP_UP(ti, ti.data(), (size_t)nnz * sizeof(int));
+  SP_UP(tsrc, tsrc.data(), (size_t)nnz * sizeof(int));
+#undef SP_UP
+  if (M->tval.ensure(std::max<size_t>((size_t)nnz * sizeof(double), 16)) != hipSuccess ||
+      M->dx.ensure(std::max<size_t>((size_t)std::max(num_rows, num_cols) * sizeof(double), 16)) != hipSuccess ||
+      M->dy.ensure(std::max<size_t>((size_t)std::max(num_rows, num_cols) * sizeof(double), 16)) != hipSuccess) {
+    h->error = "hipfact_spmat_create: out of device memory";
+    return fail(HIPFACT_ENOMEM);
+  }
+  if (nnz > 0)
+    hipLaunchKernelGGL(k_gather, dim3(nblocks(nnz, 1 << 16)), dim3(FB), 0, st, nnz, M->tsrc.as<int>(),
+                       M->val.as<double>(), M->tval.as<double>());
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    h->error = "hipfact_spmat_create: device error";
+    return fail(HIPFACT_EDEVICE);
+  }
+  *out = M;
+  return HIPFACT_OK;
+}
+
+int hipfact_spmat_update_values(hipfact_spmat* M, const double* vals) {
+  if (!M || !vals) return HIPFACT_EINVAL;
+  hipfact_handle* h = M->h;
+  int rc = enter(h);
+  if (rc) return rc;
+  if (M->nnz == 0) return HIPFACT_OK;
+  HCHECK(h, hipMemcpy(M->val.p, vals, (size_t)M->nnz * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_gather, dim3(nblocks(M->nnz, 1 << 16)), dim3(FB), 0, h->stream, M->nnz, M->tsrc.as<int>(),
+                     M->val.as<double>(), M->tval.as<double>());
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  return HIPFACT_OK;
+}
+
+int hipfact_spmat_free(hipfact_spmat** M) {
+  if (M && *M) {
+    (void)hipSetDevice((*M)->h->device);
+    delete *M;
+    *M = nullptr;
+  }
+  return HIPFACT_OK;
+}
+
+int hipfact_spmat_mult_device(hipfact_spmat* M, int trans, const double* d_x, double* d_y) {
+  if (!M || !d_x || !d_y || trans < 0 || trans > 2) return HIPFACT_EINVAL;
+  hipfact_handle* h = M->h;
+  int rc = enter(h);
+  if (rc) return rc;
+  if (trans == 2 && M->rows != M->cols) {
+    h->error = "symmetric product needs a square matrix";
+    return HIPFACT_EINVAL;
+  }
+  const int nrows = (trans == 1) ? M->cols : M->rows;
+  if (nrows == 0) return HIPFACT_OK;
+  const int* ptr = (trans == 1) ? M->cp.as<int>() : M->tp.as<int>();
+  const int* idx = (trans == 1) ? M->ri.as<int>() : M->ti.as<int>();
+  const double* val = (trans == 1) ? M->val.as<double>() : M->tval.as<double>();
+  const int* ptr2 = (trans == 2) ? M->cp.as<int>() : nullptr;
+  const int* idx2 = (trans == 2) ? M->ri.as<int>() : nullptr;
+  const double* val2 = (trans == 2) ? M->val.as<double>() : nullptr;
+  const double avg = (double)M->nnz * (trans == 2 ? 2.0 : 1.0) / std::max(nrows, 1);
+  hipStream_t st = h->stream;
+  if (avg <= 2.5)
+    launch_spmv<1>(st, nrows, ptr, idx, val, ptr2, idx2, val2, d_x, d_y);
+  else if (avg <= 10.0)
+    launch_spmv<4>(st, nrows, ptr, idx, val, ptr2, idx2, val2, d_x, d_y);
+  else if (avg <= 48.0)
+    launch_spmv<16>(st, nrows, ptr, idx, val, ptr2, idx2, val2, d_x, d_y);
+  else
+    launch_spmv<64>(st, nrows, ptr, idx, val, ptr2, idx2, val2, d_x, d_y);
+  HCHECK(h, hipGetLastError());
+  return HIPFACT_OK;
+}
+
+static int spmat_host_mult(hipfact_spmat* M, int trans, const double* x, double* y) {
+  if (!M || !x || !y) return HIPFACT_EINVAL;
+  hipfact_handle* h = M->h;
+  int rc = enter(h);
+  if (rc) return rc;
+  const int nin = (trans == 1) ? M->rows : M->cols;
+  const int nout = (trans == 1) ? M->cols : M->rows;
+  if (nin > 0) HCHECK(h, hipMemcpyAsync(M->dx.p, x, (size_t)nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if ((rc = hipfact_spmat_mult_device(M, trans, M->dx.as<double>(), M->dy.as<double>()))) return rc;
+  if (nout > 0) HCHECK(h, hipMemcpyAsync(y, M->dy.p, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  return HIPFACT_OK;
+}
+
+int hipfact_spmat_mult_vec(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 0, x, y); }
+int hipfact_spmat_mult_vec_trans(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 1, x, y); }
+int hipfact_spmat_mult_vec_sym(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 2, x, y); }
+
+// ---------------------------------------------------------------------------
+int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
+  if (!h || !name) return HIPFACT_EINVAL;
+  if (!strcmp(name, "refine_steps")) {
+    h->refine_steps = std::max(0, (int)value);
+    return HIPFACT_OK;
+  }
+  bool plan_opt = true;
+  if (!strcmp(name, "ordering"))
+    h->prm.ordering = (int)value;
+  else if (!strcmp(name, "wmax"))
+    h->prm.wmax = (int)value;
+  else if (!strcmp(name, "nd_leaf"))
+    h->prm.nd_leaf = (int)value;
+  else if (!strcmp(name, "nd_sep_frac"))
+    h->prm.nd_sep_frac = value;
+  else if (!strcmp(name, "force_generic"))
+    h->prm.force_generic = value != 0.0;
+  else
+    plan_opt = false;
+  if (plan_opt) {
+    h->have_plan = false;  // next set_matrix re-analyses
+    h->factored = false;
+    return HIPFACT_OK;
+  }
+  h->error = std::string("unknown option: ") + name;
+  return HIPFACT_EINVAL;
+}
+
+int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
+  if (!h || !name || !value) return HIPFACT_EINVAL;
+  const Plan& P = h->plan;
+#define INFO(key, expr)       \
+  if (!strcmp(name, key)) {   \
+    *value = (double)(expr);  \
+    return HIPFACT_OK;        \
+  }
+  INFO("N", P.N) INFO("n", P.n) INFO("m", P.m) INFO("saddle", P.saddle) INFO("nnzK", P.nnzK) INFO("nnzL", P.nnzL)
+  INFO("nnzL_true", P.nnzL_true) INFO("flops", P.flops) INFO("flops_dense", P.flops_dense) INFO("nsuper", P.nsuper)
+  INFO("nlevels", P.nlevels) INFO("nprod", P.nprod) INFO("L_bytes", P.L_size * 8.0) INFO("U_bytes", P.U_size * 8.0)
+  INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
+  INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
+  INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("num_solve", h->num_solve) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
+  INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
+  INFO("rows_total", P.sn_rows.size())
+#undef INFO
+  return HIPFACT_EINVAL;
+}
+
+}  // extern "C"

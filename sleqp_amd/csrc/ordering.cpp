@@ -1,0 +1,452 @@
+// Fill-reducing orderings for the hipfact KKT backend (host side, cached per
+// sparsity pattern).
+//
+// The reference delegates ordering to its third-party solvers (MA57: AMD/MC47,
+// fact_ma57.c:761-763; MA86/MA97: mc68_order, fact_ma86.c:200, fact_ma97.c:280;
+// CHOLMOD default ordering, fact_cholmod.c:133).  This backend owns it:
+//   * amd_order: quotient-graph approximate minimum degree.
+//   * nd_order : recursive level-structure nested dissection with minimum
+//                degree leaves.  Nested dissection is what makes the
+//                elimination tree short and bushy, i.e. what gives the
+//                level-scheduled device factorisation / solves their
+//                parallelism.
+#include "graph.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace hipfact {
+
+namespace {
+
+enum : uint8_t { ST_VAR = 0, ST_ELEM = 1, ST_DEAD = 2, ST_ABSORBED = 3 };
+
+struct DegLists {
+  std::vector<int> head, next, prev;
+  int mindeg;
+  explicit DegLists(int n) : head(n + 1, -1), next(n, -1), prev(n, -1), mindeg(n) {}
+  void insert(int i, int d) {
+    next[i] = head[d];
+    prev[i] = -1;
+    if (head[d] != -1) prev[head[d]] = i;
+    head[d] = i;
+    if (d < mindeg) mindeg = d;
+  }
+  void remove(int i, int d) {
+    if (prev[i] != -1)
+      next[prev[i]] = next[i];
+    else
+      head[d] = next[i];
+    if (next[i] != -1) prev[next[i]] = prev[i];
+    next[i] = prev[i] = -1;
+  }
+};
+
+}  // namespace
+
+void amd_order(const Graph& g, std::vector<int>& perm) {
+  const int n = g.n;
+  perm.clear();
+  perm.reserve(n);
+  if (n == 0) return;
+
+  std::vector<std::vector<int>> avar(n), aelm(n), evars(n);
+  std::vector<uint8_t> status(n, ST_VAR);
+  std::vector<int> nv(n, 1), degree(n), esize(n, 0);
+  std::vector<int> mark(n, 0), wflag(n, 0), w(n, 0);
+  // supervariable member chains (for the final ordering)
+  std::vector<int> chain_next(n, -1), chain_tail(n);
+  std::iota(chain_tail.begin(), chain_tail.end(), 0);
+
+  DegLists dl(n);
+  for (int i = 0; i < n; ++i) {
+    avar[i].assign(g.adj.begin() + g.ptr[i], g.adj.begin() + g.ptr[i + 1]);
+    degree[i] = (int)avar[i].size();
+    dl.insert(i, degree[i]);
+  }
+
+  int tag = 0, wtag = 0, nel = 0;
+  std::vector<int> Lp;
+  std::vector<std::pair<uint32_t, int>> hashes;
+
+  while (nel < n) {
+    // ---- pick pivot of minimum approximate degree
+    while (dl.head[dl.mindeg] == -1) ++dl.mindeg;
+    const int p = dl.head[dl.mindeg];
+    dl.remove(p, degree[p]);
+
+    // ---- form the new element L_p
+    ++tag;
+    mark[p] = tag;
+    Lp.clear();
+    for (int v : avar[p])
+      if (status[v] == ST_VAR && nv[v] > 0 && mark[v] != tag) {
+        mark[v] = tag;
+        Lp.push_back(v);
+      }
+    for (int e : aelm[p]) {
+      if (status[e] != ST_ELEM) continue;
+      for (int v : evars[e])
+        if (status[v] == ST_VAR && nv[v] > 0 && mark[v] != tag) {
+          mark[v] = tag;
+          Lp.push_back(v);
+        }
+      status[e] = ST_DEAD;  // absorbed into p
+      std::vector<int>().swap(evars[e]);
+    }
+    std::vector<int>().swap(avar[p]);
+    std::vector<int>().swap(aelm[p]);
+    status[p] = ST_ELEM;
+    nel += nv[p];
+    const int nleft = n - nel;
+    int degme = 0;
+    for (int v : Lp) {
+      degme += nv[v];
+      dl.remove(v, degree[v]);
+    }
+    esize[p] = degme;
+
+    // ---- prune adjacency of the members, attach the new element
+    for (int i : Lp) {
+      auto& ae = aelm[i];
+      size_t k = 0;
+      for (int e : ae)
+        if (status[e] == ST_ELEM && e != p) ae[k++] = e;
+      ae.resize(k);
+      auto& av = avar[i];
+      k = 0;
+      for (int v : av)
+        if (status[v] == ST_VAR && nv[v] > 0 && mark[v] != tag) av[k++] = v;
+      av.resize(k);
+    }
+
+    // ---- |L_e \ L_p| for every element adjacent to a member
+    ++wtag;
+    for (int i : Lp)
+      for (int e : aelm[i]) {
+        if (wflag[e] != wtag) {
+          wflag[e] = wtag;
+          w[e] = esize[e];
+        }
+        w[e] -= nv[i];
+      }
+
+    // ---- approximate degrees, aggressive absorption, hashing
+    hashes.clear();
+    for (int i : Lp) {
+      auto& ae = aelm[i];
+      size_t k = 0;
+      long long deg = 0;
+      uint32_t h = 0;
+      for (int e : ae) {
+        if (status[e] != ST_ELEM) continue;
+        if (w[e] <= 0) {  // L_e subset of L_p: absorb e into p
+          status[e] = ST_DEAD;
+          std::vector<int>().swap(evars[e]);
+          continue;
+        }
+        deg += w[e];
+        h += (uint32_t)e;
+        ae[k++] = e;
+      }
+      ae.resize(k);
+      ae.push_back(p);
+      h += (uint32_t)p;
+      for (int v : avar[i]) {
+        deg += nv[v];
+        h += (uint32_t)v;
+      }
+      if (deg > n) deg = n;
+      degree[i] = std::min<long long>(degree[i], deg);  // size of L_p added below
+      hashes.emplace_back(h, i);
+    }
+
+    // ---- supervariable detection among the members of L_p
+    std::sort(hashes.begin(), hashes.end());
+    for (size_t a = 0; a < hashes.size();) {
+      size_t b = a;
+      while (b < hashes.size() && hashes[b].first == hashes[a].first) ++b;
+      for (size_t s = a; s < b; ++s) {
+        const int i = hashes[s].second;
+        if (nv[i] == 0) continue;
+        ++tag;
+        for (int e : aelm[i]) mark[e] = tag;
+        // variables and elements share the id space [0,n): a vertex is either a
+        // live variable or an element, never both, so one marker array suffices
+        for (int v : avar[i]) mark[v] = tag;
+        for (size_t t = s + 1; t < b; ++t) {
+          const int j = hashes[t].second;
+          if (nv[j] == 0) continue;
+          if (aelm[j].size() != aelm[i].size() || avar[j].size() != avar[i].size()) continue;
+          bool same = true;
+          for (int e : aelm[j])
+            if (mark[e] != tag) {
+              same = false;
+              break;
+            }
+          if (same)
+            for (int v : avar[j])
+              if (mark[v] != tag) {
+                same = false;
+                break;
+              }
+          if (!same) continue;
+          // j is indistinguishable from i: merge
+          nv[i] += nv[j];
+          nv[j] = 0;
+          status[j] = ST_ABSORBED;
+          chain_next[chain_tail[i]] = j;
+          chain_tail[i] = chain_tail[j];
+          std::vector<int>().swap(avar[j]);
+          std::vector<int>().swap(aelm[j]);
+        }
+      }
+      a = b;
+    }
+
+    // ---- finalise degrees, rebuild element member list without absorbed vars
+    {
+      size_t k = 0;
+      for (int i : Lp) {
+        if (nv[i] == 0) continue;
+        long long d = (long long)degree[i] + degme - nv[i];
+        d = std::min<long long>(d, nleft - nv[i]);
+        if (d < 0) d = 0;
+        degree[i] = (int)d;
+        dl.insert(i, degree[i]);
+        Lp[k++] = i;
+      }
+      Lp.resize(k);
+      evars[p] = Lp;
+    }
+
+    // ---- emit p and the variables merged into it
+    for (int v = p; v != -1; v = chain_next[v]) perm.push_back(v);
+  }
+  assert((int)perm.size() == n);
+}
+
+// ---------------------------------------------------------------------------
+// nested dissection
+// ---------------------------------------------------------------------------
+namespace {
+
+struct NDState {
+  const Graph& g;
+  NDParams prm;
+  std::vector<int> inset;  // stamp: vertex belongs to the current subset
+  std::vector<int> level;  // BFS level / scratch
+  std::vector<int> local;  // global -> local index for leaf subgraphs
+  int stamp = 0;
+  std::vector<int>& perm;
+  NDState(const Graph& g_, const NDParams& p, std::vector<int>& out)
+      : g(g_), prm(p), inset(g_.n, -1), level(g_.n, -1), local(g_.n, -1), perm(out) {}
+
+  void leaf(const std::vector<int>& verts) {
+    const int k = (int)verts.size();
+    if (k <= 2) {
+      for (int v : verts) perm.push_back(v);
+      return;
+    }
+    for (int t = 0; t < k; ++t) local[verts[t]] = t;
+    Graph sub;
+    sub.n = k;
+    sub.ptr.assign(k + 1, 0);
+    const int id = ++stamp;
+    for (int v : verts) inset[v] = id;
+    for (int t = 0; t < k; ++t) {
+      const int v = verts[t];
+      int64_t c = 0;
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
+        if (inset[g.adj[q]] == id) ++c;
+      sub.ptr[t + 1] = sub.ptr[t] + c;
+    }
+    sub.adj.resize(sub.ptr[k]);
+    for (int t = 0; t < k; ++t) {
+      const int v = verts[t];
+      int64_t o = sub.ptr[t];
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
+        if (inset[g.adj[q]] == id) sub.adj[o++] = local[g.adj[q]];
+    }
+    std::vector<int> lp;
+    amd_order(sub, lp);
+    for (int t : lp) perm.push_back(verts[t]);
+  }
+
+  // BFS inside the stamped subset from root; returns vertices in BFS order and
+  // fills level[]; lev_ptr delimits the level sets.
+  void bfs(int root, int id, std::vector<int>& order, std::vector<int>& lev_ptr) {
+    order.clear();
+    lev_ptr.clear();
+    order.push_back(root);
+    level[root] = 0;
+    inset[root] = -id;  // visited marker (negated stamp)
+    lev_ptr.push_back(0);
+    size_t head = 0;
+    int cur = 0;
+    while (head < order.size()) {
+      const int v = order[head];
+      if (level[v] != cur) {
+        cur = level[v];
+        lev_ptr.push_back((int)head);
+      }
+      ++head;
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+        const int u = g.adj[q];
+        if (inset[u] == id) {
+          inset[u] = -id;
+          level[u] = cur + 1;
+          order.push_back(u);
+        }
+      }
+    }
+    lev_ptr.push_back((int)order.size());
+    for (int v : order) inset[v] = id;  // restore
+  }
+
+  void rec(std::vector<int> verts) {
+    const int k = (int)verts.size();
+    if (k <= prm.leaf_size) {
+      leaf(verts);
+      return;
+    }
+    const int id = ++stamp;
+    for (int v : verts) inset[v] = id;
+
+    // ---- connected components
+    std::vector<int> order, lev_ptr;
+    {
+      std::vector<std::vector<int>> comps;
+      const int cid = ++stamp;  // component-visited stamp
+      std::vector<int> queue;
+      for (int s : verts) {
+        if (inset[s] != id) continue;
+        queue.clear();
+        queue.push_back(s);
+        inset[s] = cid;
+        for (size_t h = 0; h < queue.size(); ++h) {
+          const int v = queue[h];
+          for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+            const int u = g.adj[q];
+            if (inset[u] == id) {
+              inset[u] = cid;
+              queue.push_back(u);
+            }
+          }
+        }
+        if ((int)queue.size() == k) break;  // single component
+        comps.push_back(queue);
+      }
+      if (!comps.empty()) {
+        std::vector<int>().swap(verts);
+        for (auto& c : comps) rec(std::move(c));
+        return;
+      }
+      for (int v : verts) inset[v] = id;
+    }
+
+    // ---- pseudo-peripheral root
+    int root = verts[0];
+    {
+      int64_t best = INT64_MAX;
+      for (int v : verts) {
+        const int64_t d = g.ptr[v + 1] - g.ptr[v];
+        if (d < best) {
+          best = d;
+          root = v;
+        }
+      }
+    }
+    int ecc = -1;
+    for (int it = 0; it < 6; ++it) {
+      bfs(root, id, order, lev_ptr);
+      const int nlev = (int)lev_ptr.size() - 1;
+      if (nlev - 1 <= ecc) break;
+      ecc = nlev - 1;
+      // min-degree vertex of the last level
+      int cand = order[lev_ptr[nlev - 1]];
+      int64_t best = INT64_MAX;
+      for (int t = lev_ptr[nlev - 1]; t < lev_ptr[nlev]; ++t) {
+        const int v = order[t];
+        const int64_t d = g.ptr[v + 1] - g.ptr[v];
+        if (d < best) {
+          best = d;
+          cand = v;
+        }
+      }
+      if (cand == root) break;
+      root = cand;
+    }
+    bfs(root, id, order, lev_ptr);
+    const int nlev = (int)lev_ptr.size() - 1;
+    if (nlev < 3) {
+      leaf(verts);
+      return;
+    }
+
+    // ---- choose the separator level: smallest level set among balanced cuts
+    int best_l = -1;
+    double best_cost = 1e300;
+    for (int l = 1; l + 1 < nlev; ++l) {
+      const int before = lev_ptr[l];
+      const int sz = lev_ptr[l + 1] - lev_ptr[l];
+      const int after = k - before - sz;
+      const int small = std::min(before, after);
+      if (small < prm.balance * k) continue;
+      const double cost = (double)sz * (1.0 + 0.5 * std::abs(before - after) / (double)k);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best_l = l;
+      }
+    }
+    if (best_l < 0) {
+      leaf(verts);
+      return;
+    }
+    const int sep_sz = lev_ptr[best_l + 1] - lev_ptr[best_l];
+    if (sep_sz > prm.max_sep_frac * k) {
+      leaf(verts);
+      return;
+    }
+
+    std::vector<int> left(order.begin(), order.begin() + lev_ptr[best_l]);
+    std::vector<int> right(order.begin() + lev_ptr[best_l + 1], order.end());
+    std::vector<int> sep;
+    sep.reserve(sep_sz);
+    // trim: separator vertices without a neighbour in the next level go left
+    for (int t = lev_ptr[best_l]; t < lev_ptr[best_l + 1]; ++t) {
+      const int v = order[t];
+      bool touches = false;
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1] && !touches; ++q) {
+        const int u = g.adj[q];
+        touches = (inset[u] == id && level[u] == best_l + 1);
+      }
+      if (touches)
+        sep.push_back(v);
+      else
+        left.push_back(v);
+    }
+    std::vector<int>().swap(verts);
+    std::vector<int>().swap(order);
+    rec(std::move(left));
+    rec(std::move(right));
+    for (int v : sep) perm.push_back(v);
+  }
+};
+
+}  // namespace
+
+void nd_order(const Graph& g, const NDParams& p, std::vector<int>& perm) {
+  perm.clear();
+  perm.reserve(g.n);
+  NDState st(g, p, perm);
+  std::vector<int> all(g.n);
+  std::iota(all.begin(), all.end(), 0);
+  st.rec(std::move(all));
+  assert((int)perm.size() == g.n);
+}
+
+}  // namespace hipfact

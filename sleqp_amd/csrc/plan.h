@@ -1,0 +1,101 @@
+// Symbolic plan of the hipfact KKT backend: everything the device numeric
+// phase needs, computed on the host once per sparsity pattern of K and cached.
+//
+// K is the lower-triangular CSC matrix handed to SLEQP_FACT_SET_MATRIX
+// (reference fact/fact_types.h:9-10), built by fill_aug_jac
+// (aug_jac/standard_aug_jac.c:135-237):  K = [ I  A^T ; A  0 ],  N = n + m.
+//
+// Saddle mode (K has exactly that shape, unit (1,1) block): the LDL^T of K
+// under the constrained pivot order "every x before every y" is
+//     L = [ I 0 ; A  L_s ],  D = diag(I, -D_s),  L_s D_s L_s^T = S = A A^T,
+// so no pivot is ever zero (A has full row rank, pub_working_set.h:42-44) and the
+// x columns are structurally trivial leaf supernodes.  They are eliminated by
+// one product-list kernel (S values), the remaining m columns by a supernodal
+// multifrontal LDL^T over the elimination tree of S; the x part of a solve is
+// two SpMVs with A.
+//
+// Generic mode (anything else, e.g. an SPD / quasi-definite matrix): the same
+// supernodal engine runs on M = K itself with static 1x1 pivots.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace hipfact {
+
+struct PlanParams {
+  int ordering = 0;        // 0 = nested dissection + AMD leaves, 1 = AMD only, 2 = natural
+  int nd_leaf = 0;         // 0 = automatic
+  double nd_sep_frac = 0.2;
+  int wmax = 128;          // widest supernode (diagonal block is LDS resident)
+  double relax_small = 0.5;   // allowed explicit-zero fraction, merged width <= 32
+  double relax_mid = 0.25;    // ... <= 64
+  double relax_big = 0.10;    // ... wider
+  bool force_generic = false;
+};
+
+struct Plan {
+  // ---- problem
+  int N = 0;  // dimension of K
+  int n = 0;  // saddle: number of x columns; generic: 0
+  int m = 0;  // order of M (saddle: constraints, generic: N)
+  bool saddle = false;
+  int64_t nnzK = 0;
+  std::vector<int> Kp, Ki;  // pattern of K the plan was built for (cache key)
+
+  // ---- pivot order of M: perm[k] = original index of the k-th pivot
+  std::vector<int> perm, iperm;
+
+  // ---- M in pivot order, lower CSC (diagonal first in each column)
+  std::vector<int64_t> Mp;  // m+1
+  std::vector<int> Mi;      // row indices (pivot order)
+  std::vector<int64_t> Mtarget;  // per entry: offset into the L arena
+
+  // value sources.  saddle: M[e] = sum_t Kval[prod_a[t]] * Kval[prod_b[t]],
+  // t in [prod_ptr[e], prod_ptr[e+1]).  generic: M[e] = Kval[src[e]] (-1: 0).
+  std::vector<int64_t> prod_ptr;
+  std::vector<int> prod_a, prod_b;
+  std::vector<int> src;
+
+  // ---- supernodes (fronts)
+  int nsuper = 0;
+  std::vector<int> sn_c0;       // nsuper+1 first column of each supernode
+  std::vector<int> sn_r;        // rows in front (including own columns)
+  std::vector<int64_t> sn_rowptr;  // nsuper+1 into sn_rows
+  std::vector<int> sn_rows;     // sorted row structure, own columns first
+  std::vector<int> sn_parent;   // -1 root
+  std::vector<int> sn_level;    // 0 = leaf
+  std::vector<int64_t> sn_Loff;  // panel offset in L arena (r x w, ld = r)
+  std::vector<int64_t> sn_Uoff;  // update-matrix offset in U arena (u x u, ld = u)
+  std::vector<int64_t> sn_uoff;  // update-vector offset (solve), length u
+  std::vector<int> child_ptr, child_idx;  // children lists
+  std::vector<int64_t> rel_ptr;  // nsuper+1 into rel (length u each)
+  std::vector<int> rel;          // position of each below-row in the parent's front
+  int nlevels = 0;
+  std::vector<int> level_ptr, level_sn;  // supernodes grouped by level
+  int64_t L_size = 0, U_size = 0, u_size = 0;
+
+  // ---- saddle-mode SpMV structures
+  std::vector<int> Ar_ptr;   // m+1: CSR of A with rows in pivot order
+  std::vector<int> Ar_col;   // column (x index)
+  std::vector<int> Ar_src;   // index into Kval
+  std::vector<int> Kc_y;     // per K entry in columns < n: pivot position of its y row, -1 for the diagonal
+
+  // ---- statistics
+  int64_t nnzL = 0;       // entries of L incl. diagonal (M part, dense panels)
+  int64_t nnzL_true = 0;  // same without relaxation zeros (column counts)
+  double flops = 0;       // sum_j c_j^2 (true column counts)
+  double flops_dense = 0; // flops executed on the dense fronts
+  int64_t nprod = 0;
+  int max_r = 0, max_w = 0, max_u = 0;
+  double t_order = 0, t_symbolic = 0, t_total = 0;
+  std::string error;
+};
+
+// Builds the plan for the pattern (N, Kp, Ki) of a lower-triangular CSC matrix.
+// Kx may be null (pattern-only: the unit-diagonal test is then skipped).
+// Returns false and sets plan.error on failure.
+bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx,
+                const PlanParams& prm, Plan& plan);
+
+}  // namespace hipfact
