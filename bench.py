@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""KKT factor+solve benchmark (BASELINE.json metric) for the hipfact backend.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic KKT system whose data
+is already resident in HBM: numeric refactorisation of K (SLEQP_FACT_SET_MATRIX
+with an unchanged sparsity pattern, i.e. the steady state of an SQP run) plus
+one solve K z = b with iterative refinement (SLEQP_FACT_SOLVE).  Workload at
+N=1: BASELINE.json configs[3] (n=1e5, m=5e4, nnz(J)=1e6 `banded`, SURVEY.md
+§8d).  For N>1 every rank factors an independent problem (seed = rank) on its
+own GPU — BASELINE.json configs[4]; there is no data-path collective
+("replicas only"), torch.distributed (RCCL) is used for the
+barrier and the max-over-ranks reduction only.
+
+Prints ONE JSON line on rank 0 (contract in the task description) carrying
+`roofline` (dominant kernel, HIP-event timed on the handle's own stream) and
+`cpu_baseline` (the oracle's simplicial sparse LDL^T on the host, rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_problem(workload: str, seed: int):
+    from sleqp_amd import synth
+
+    if workload == "banded_n1e5_m5e4":
+        J = synth.banded_jacobian(100000, 50000, 20, 200, seed)
+    elif workload == "banded_n1e4_m5e3":
+        J = synth.banded_jacobian(10000, 5000, 20, 200, seed)
+    elif workload == "uniform_n1e4_m5e3":
+        J = synth.uniform_jacobian(10000, 5000, 10, seed)
+    elif workload == "tiny":
+        J = synth.banded_jacobian(400, 200, 8, 60, seed)
+    else:
+        raise ValueError(workload)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    b = np.random.default_rng(seed + 1).standard_normal(N)
+    return J, N, cp, ri, vx, b
+
+
+def algorithmic_bytes(fact):
+    """SURVEY.md §8(d) figures from the backend's own symbolic analysis."""
+    nnzK = fact.info("nnzK")
+    nnzL = fact.info("nnzL") + fact.info("n") + (fact.info("nnzK") - fact.info("n") if fact.info("saddle") else 0)
+    # stored row indices: one list per supernode (+ A's indices in saddle mode)
+    nnz_idx = fact.info("rows_total") + (fact.info("nnzK") if fact.info("saddle") else 0)
+    N = fact.info("N")
+    factor = 12 * nnzK + 16 * nnzL + 4 * nnz_idx
+    solve = 2 * (8 * nnzL + 4 * nnz_idx) + 8 * N + 3 * 8 * N
+    return factor, solve, nnzL
+
+
+def cpu_baseline(N, cp, ri, vx, b, budget_s=20.0):
+    """Oracle (oracle/kkt_oracle.c) simplicial LDL^T, single thread, x-before-y natural order."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle  # test infrastructure; only the baseline leg uses it
+
+    reps, t_total = 0, 0.0
+    t_factor = t_solve = 0.0
+    while reps < 1 or (t_total < budget_s and reps < 50):
+        t0 = time.perf_counter()
+        F = oracle.OracleLdl(N, cp, ri, vx)
+        t1 = time.perf_counter()
+        F.solve(b)
+        t2 = time.perf_counter()
+        t_factor += t1 - t0
+        t_solve += t2 - t1
+        t_total += t2 - t0
+        reps += 1
+        del F
+    return {
+        "value": reps / t_total,
+        "unit": "factor+solve/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} x (numeric+symbolic simplicial LDL^T + 1 solve) of the same K on 1 host core, "
+                  f"factor {t_factor / reps * 1e3:.1f} ms, solve {t_solve / reps * 1e3:.2f} ms",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="banded_n1e5_m5e4")
+    ap.add_argument("--refine", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solves-per-factor", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hipfact backend has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    J, N, cp, ri, vx, b = make_problem(args.workload, seed=rank)
+    fact = HipFact(device=local_rank, refine_steps=args.refine)
+    t0 = time.perf_counter()
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))  # cold call: analysis + upload + first factorisation
+    fact.synchronize()
+    t_cold = time.perf_counter() - t0
+    d_vals = torch.from_numpy(vx).to(dev)
+    d_rhs = torch.from_numpy(b).to(dev)
+    d_sol = torch.empty_like(d_rhs)
+    torch.cuda.synchronize()
+
+    def step():
+        fact.refactor_device(d_vals.data_ptr())
+        for _ in range(args.solves_per_factor):
+            fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        fact.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fact.synchronize()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([t_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+    else:
+        t_max = t_local
+
+    # correctness of what was timed (scaled residual of the last solve)
+    from sleqp_amd import synth
+
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    z = d_sol.cpu().numpy()
+    resid = float(np.abs(K @ z - b).max() / (abs(K).sum(axis=1).max() * np.abs(z).max() + np.abs(b).max()))
+
+    # ---- per-kernel-class timing with HIP events on the handle's stream
+    fact.set_option("profile", -1)
+    fact.set_option("profile", 1)
+    prof_steps = max(3, min(args.steps, 10))
+    for _ in range(prof_steps):
+        step()
+    fact.synchronize()
+    prof = {}
+    for cls in ("memset", "mvals", "gather", "factor", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"):
+        ms, cnt = fact.info(f"prof_{cls}_ms"), fact.info(f"prof_{cls}_count")
+        if cnt > 0:
+            prof[cls] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps,
+                         "avg_launch_us": ms / cnt * 1e3}
+    fact.set_option("profile", 0)
+
+    # ---- solve-only rate (the real ratio is ~1 factor : 100 solves, trlib_solver.c:768-776)
+    nsolve = 50
+    fact.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsolve):
+        fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+    fact.synchronize()
+    t_solve = (time.perf_counter() - t0) / nsolve
+
+    if rank == 0:
+        fbytes, sbytes, nnzL = algorithmic_bytes(fact)
+        dom = max(prof, key=lambda k: prof[k]["ms_per_step"]) if prof else "factor"
+        kernel_names = {"factor": "k_factor_level", "fwd": "k_fwd_level", "bwd": "k_bwd_level", "mvals": "k_mvals_prod",
+                        "memset": "hipMemsetAsync(L arena)"}
+        if dom == "factor":
+            # one factorisation = nlevels launches of k_factor_level; algorithmic bytes per launch
+            launches = prof[dom]["launches_per_step"]
+            bytes_per_launch = fbytes / launches
+        elif dom in ("fwd", "bwd"):
+            launches = prof[dom]["launches_per_step"]
+            bytes_per_launch = (sbytes / 2) * (1 + args.refine) * args.solves_per_factor / launches
+        else:
+            launches = prof[dom]["launches_per_step"]
+            bytes_per_launch = fbytes / max(launches, 1)
+        avg_s = prof[dom]["avg_launch_us"] * 1e-6
+        achieved = bytes_per_launch / avg_s / 1e9
+        out = {
+            "metric": "KKT factor+solve/sec (numeric refactor + 1 refined solve, inputs resident in HBM)",
+            "value": world * args.steps / t_max,
+            "unit": "factor+solve/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "n": int(fact.info("n")), "m": int(fact.info("m")), "N": N,
+                       "nnz_J": int(J.nnz), "nnz_tril_K": int(fact.info("nnzK")), "nnz_L": int(nnzL),
+                       "supernodes": int(fact.info("nsuper")), "etree_levels": int(fact.info("nlevels")),
+                       "refine_steps": args.refine, "solves_per_factor": args.solves_per_factor,
+                       "parallelism": f"replicas{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": kernel_names.get(dom, dom), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": prof[dom]["avg_launch_us"]},
+            "kernels": prof,
+            "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3,
+                           "algorithmic_GBps": sbytes * (1 + args.refine) / t_solve / 1e9},
+            "factor_only_ms": sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor") if k in prof),
+            "cold_set_matrix_s": t_cold,
+            "analysis_s": fact.info("analysis_s"),
+            "scaled_residual": resid,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, cp, ri, vx, b)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,23 @@ struct LevelInfo {
   size_t lds_factor = 0, lds_fwd = 0, lds_bwd = 0;
 };
 
+// kernel classes for the event-timed profiling mode (option "profile")
+enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
+static const char* const kProfNames[PC_COUNT] = {"memset", "mvals", "gather", "factor", "fwd", "bwd",
+                                                 "rhs",    "xupd",  "resid",  "axpy",   "perm"};
+
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs (start, stop)
+  std::vector<int> cls;
+  size_t used = 0;
+  double ms[PC_COUNT] = {0};
+  long cnt[PC_COUNT] = {0};
+  ~Prof() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+
 }  // namespace hipfact
 
 using namespace hipfact;
@@ -89,6 +106,7 @@ struct hipfact_handle {
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
+  Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
@@ -123,6 +141,46 @@ static inline int nblocks(long long n, int cap = 4096) {
   if (b > cap) b = cap;
   return (int)b;
 }
+
+static void prof_begin(hipfact_handle* h, int cls) {
+  Prof& p = h->prof;
+  if (!p.on) return;
+  if (p.used + 2 > p.ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    p.ev.push_back(a);
+    p.ev.push_back(b);
+  }
+  p.cls.resize(p.ev.size() / 2);
+  p.cls[p.used / 2] = cls;
+  (void)hipEventRecord(p.ev[p.used], h->stream);
+}
+static void prof_end(hipfact_handle* h) {
+  Prof& p = h->prof;
+  if (!p.on || p.used + 2 > p.ev.size()) return;
+  (void)hipEventRecord(p.ev[p.used + 1], h->stream);
+  p.used += 2;
+}
+static void prof_collect(hipfact_handle* h) {
+  Prof& p = h->prof;
+  if (p.used == 0) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (size_t i = 0; i < p.used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+      p.ms[p.cls[i / 2]] += ms;
+      p.cnt[p.cls[i / 2]] += 1;
+    }
+  }
+  p.used = 0;
+}
+// launch wrapper: LAUNCH(class, kernel, grid, block, lds, args...)
+#define LAUNCH(cls, kernel, grid, block, lds, ...)                         \
+  do {                                                                     \
+    prof_begin(h, cls);                                                    \
+    hipLaunchKernelGGL(kernel, grid, block, lds, h->stream, __VA_ARGS__);  \
+    prof_end(h);                                                           \
+  } while (0)
 
 template <class T>
 static int upload(hipfact_handle* h, DevBuf& buf, const std::vector<T>& v) {
@@ -241,26 +299,30 @@ static int factor_async(hipfact_handle* h) {
   const Plan& P = h->plan;
   hipStream_t st = h->stream;
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_WORDS * sizeof(int), st));
-  if (P.L_size > 0) HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double), st));
+  if (P.L_size > 0) {
+    prof_begin(h, PC_MEMSET);
+    HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double), st));
+    prof_end(h);
+  }
   const long long nM = (long long)P.Mi.size();
   if (nM > 0) {
     if (P.saddle) {
-      hipLaunchKernelGGL(k_mvals_prod, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, st, nM,
+      LAUNCH(PC_MVALS, k_mvals_prod, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
                          h->d_prod_ptr.as<long long>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
     } else {
-      hipLaunchKernelGGL(k_mvals_src, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, st, nM, h->d_src.as<int>(),
+      LAUNCH(PC_MVALS, k_mvals_src, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM, h->d_src.as<int>(),
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
     }
   }
   if (P.saddle && !P.Ar_src.empty()) {
     const long long na = (long long)P.Ar_src.size();
-    hipLaunchKernelGGL(k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, st, na, h->d_Ar_src.as<int>(),
+    LAUNCH(PC_GATHER, k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, na, h->d_Ar_src.as<int>(),
                        h->d_Kval.as<double>(), h->d_Ar_val.as<double>());
   }
   for (int l = 0; l < P.nlevels; ++l) {
     const LevelInfo& li = h->levels[l];
-    hipLaunchKernelGGL(k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, st, h->d_sn.as<SnDesc>(),
+    LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(),
                        h->d_rel.as<int>(), h->d_child.as<int>(), h->d_info.as<int>());
   }
@@ -287,16 +349,15 @@ static int check_info(hipfact_handle* h) {
 // M y = t on the device (y in: t in pivot order, out: solution)
 static void solve_m_async(hipfact_handle* h) {
   const Plan& P = h->plan;
-  hipStream_t st = h->stream;
   for (int l = 0; l < P.nlevels; ++l) {
     const LevelInfo& li = h->levels[l];
-    hipLaunchKernelGGL(k_fwd_level, dim3(li.count), dim3(FB), li.lds_fwd, st, h->d_sn.as<SnDesc>(),
+    LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(FB), li.lds_fwd, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(),
                        h->d_child.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>());
   }
   for (int l = P.nlevels - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];
-    hipLaunchKernelGGL(k_bwd_level, dim3(li.count), dim3(FB), li.lds_bwd, st, h->d_sn.as<SnDesc>(),
+    LAUNCH(PC_BWD, k_bwd_level, dim3(li.count), dim3(FB), li.lds_bwd, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(),
                        h->d_y.as<double>());
   }
@@ -305,35 +366,33 @@ static void solve_m_async(hipfact_handle* h) {
 // z = K^-1 b without refinement; b, z device vectors of length N (may alias)
 static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
-  hipStream_t st = h->stream;
   if (P.N == 0) return;
   if (P.saddle) {
     if (P.m > 0) {
-      hipLaunchKernelGGL(k_rhs_saddle, dim3(nblocks(P.m)), dim3(FB), 0, st, P.m, P.n, h->d_Ar_ptr.as<int>(),
+      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks(P.m)), dim3(FB), 0, P.m, P.n, h->d_Ar_ptr.as<int>(),
                          h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b,
                          h->d_y.as<double>());
       solve_m_async(h);
     }
-    hipLaunchKernelGGL(k_x_saddle, dim3(nblocks(P.N)), dim3(FB), 0, st, P.n, P.m, h->d_Kp.as<int>(),
+    LAUNCH(PC_XUPD, k_x_saddle, dim3(nblocks(P.N)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
                        h->d_Kval.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), h->d_y.as<double>(), b, z);
   } else {
-    hipLaunchKernelGGL(k_gather, dim3(nblocks(P.m)), dim3(FB), 0, st, (long long)P.m, h->d_perm.as<int>(), b,
+    LAUNCH(PC_PERM, k_gather, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(), b,
                        h->d_y.as<double>());
     solve_m_async(h);
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, st, (long long)P.m, h->d_perm.as<int>(),
+    LAUNCH(PC_PERM, k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
                        h->d_y.as<double>(), z);
   }
 }
 
 static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res) {
   const Plan& P = h->plan;
-  hipStream_t st = h->stream;
   if (P.saddle) {
-    hipLaunchKernelGGL(k_residual_saddle, dim3(nblocks(P.N)), dim3(FB), 0, st, P.n, P.m, h->d_Kp.as<int>(),
+    LAUNCH(PC_RESID, k_residual_saddle, dim3(nblocks(P.N)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
                        h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res);
   } else {
-    hipLaunchKernelGGL(k_residual_sym, dim3(nblocks(P.N)), dim3(FB), 0, st, P.N, h->d_Kp.as<int>(),
+    LAUNCH(PC_RESID, k_residual_sym, dim3(nblocks(P.N)), dim3(FB), 0, P.N, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(),
                        h->d_Tsrc.as<int>(), b, z, res);
   }
@@ -353,7 +412,7 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
   for (int it = 0; it < h->refine_steps; ++it) {
     residual_async(h, bb, z, h->d_res.as<double>());
     solve_once_async(h, h->d_res.as<double>(), h->d_corr.as<double>());
-    hipLaunchKernelGGL(k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, h->stream, (long long)P.N, 1.0,
+    LAUNCH(PC_AXPY, k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, (long long)P.N, 1.0,
                        h->d_corr.as<double>(), z);
   }
   HCHECK(h, hipGetLastError());
@@ -844,6 +903,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->refine_steps = std::max(0, (int)value);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "profile")) {  // event-time every kernel class; value < 0 resets the counters
+    if (h->prof.on) prof_collect(h);
+    if (value < 0)
+      for (int c = 0; c < PC_COUNT; ++c) h->prof.ms[c] = 0, h->prof.cnt[c] = 0;
+    h->prof.on = value > 0;
+    return HIPFACT_OK;
+  }
   bool plan_opt = true;
   if (!strcmp(name, "ordering"))
     h->prm.ordering = (int)value;
@@ -869,6 +935,23 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
 int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return HIPFACT_EINVAL;
   const Plan& P = h->plan;
+  if (!strncmp(name, "prof_", 5)) {  // prof_<class>_ms / prof_<class>_count
+    prof_collect(const_cast<hipfact_handle*>(h));
+    for (int c = 0; c < PC_COUNT; ++c) {
+      const size_t len = strlen(kProfNames[c]);
+      if (!strncmp(name + 5, kProfNames[c], len) && name[5 + len] == '_') {
+        if (!strcmp(name + 6 + len, "ms")) {
+          *value = h->prof.ms[c];
+          return HIPFACT_OK;
+        }
+        if (!strcmp(name + 6 + len, "count")) {
+          *value = (double)h->prof.cnt[c];
+          return HIPFACT_OK;
+        }
+      }
+    }
+    return HIPFACT_EINVAL;
+  }
 #define INFO(key, expr)       \
   if (!strcmp(name, key)) {   \
     *value = (double)(expr);  \

@@ -1,0 +1,147 @@
+"""Host-side symbolic analysis (ordering, supernodes, multifrontal maps, product
+lists) validated on the CPU: the plan is executed by the numpy emulator in
+tests/plan_emul.py and compared with a dense solve of the full K."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from plan_emul import EmulFactor, Plan
+from sleqp_amd import synth
+
+
+def _check(lib, N, cp, ri, vx, seed=0, tol=1e-9):
+    P = Plan(lib, N, cp, ri, vx)
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    b = np.random.default_rng(seed).standard_normal(N)
+    z = EmulFactor(P, vx).solve(b)
+    zr = np.linalg.solve(K.toarray(), b) if N > 0 else np.zeros(0)
+    assert np.abs(z - zr).max() <= tol * max(1.0, np.abs(zr).max()) if N > 0 else True
+    return P
+
+
+def _structure_invariants(P):
+    ns = P.nsuper
+    w = np.diff(P.sn_c0)
+    assert P.sn_c0[0] == 0 and P.sn_c0[-1] == P.m and np.all(w >= 1) and np.all(w <= 128)
+    assert sorted(P.perm.tolist()) == list(range(P.m))
+    assert np.array_equal(P.iperm[P.perm], np.arange(P.m))
+    for s in range(ns):
+        rows = P.sn_rows[P.sn_rowptr[s]:P.sn_rowptr[s + 1]]
+        assert np.all(np.diff(rows) > 0)
+        assert np.array_equal(rows[:w[s]], np.arange(P.sn_c0[s], P.sn_c0[s + 1]))
+        p = P.sn_parent[s]
+        if len(rows) > w[s]:
+            assert p > s and P.sn_c0[p] <= rows[w[s]] < P.sn_c0[p + 1]
+            assert P.sn_level[p] > P.sn_level[s]
+            prow = P.sn_rows[P.sn_rowptr[p]:P.sn_rowptr[p + 1]]
+            rel = P.rel[P.rel_ptr[s]:P.rel_ptr[s + 1]]
+            assert np.array_equal(prow[rel], rows[w[s]:])
+        else:
+            assert p == -1
+    # every level list is a partition of the supernodes
+    assert sorted(P.level_sn.tolist()) == list(range(ns))
+    # panels do not overlap
+    order = np.argsort(P.sn_Loff)
+    ends = P.sn_Loff[order] + P.sn_r[order].astype(np.int64) * w[order]
+    assert np.all(ends[:-1] <= P.sn_Loff[order][1:]) and (ns == 0 or ends[-1] <= P.L_size)
+
+
+@pytest.mark.parametrize("n,m,kind,frac", [(2, 1, "u", 0.0), (4, 2, "u", 0.5), (40, 20, "b", 0.0), (40, 20, "u", 0.2),
+                                            (300, 150, "b", 0.1), (600, 300, "u", 0.0), (900, 450, "b", 0.05)])
+def test_saddle_plan(hipfact_lib, n, m, kind, frac):
+    J = synth.banded_jacobian(n, m, min(12, n), min(80, n), 1) if kind == "b" else synth.uniform_jacobian(n, m, min(4, n), 1)
+    vi, ci, _ = synth.working_set_all_rows(n, m, frac, 1)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+    P = _check(hipfact_lib, N, cp, ri, vx)
+    assert P.saddle and P.n == n and P.m == N - n
+    _structure_invariants(P)
+
+
+def test_identity_only(hipfact_lib):
+    # empty working set: K = I (unconstrained_newton_test.c setting)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(sp.csc_matrix((0, 5)))
+    P = _check(hipfact_lib, N, cp, ri, vx)
+    assert P.saddle and P.m == 0 and P.nsuper == 0
+
+
+def test_only_active_bounds(hipfact_lib):
+    vi = np.array([0, -1, 1, -1], dtype=np.int32)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(sp.csc_matrix((0, 4)), vi, np.zeros(0, np.int32))
+    P = _check(hipfact_lib, N, cp, ri, vx)
+    assert P.saddle and P.m == 2
+
+
+def test_full_working_set(hipfact_lib):
+    # |W| = n: square A_W (pub_working_set.h: at most n active rows)
+    J = synth.uniform_jacobian(30, 30, 6, 3) + sp.eye(30) * 5
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(sp.csc_matrix(J))
+    _check(hipfact_lib, N, cp, ri, vx)
+
+
+@pytest.mark.parametrize("ordering", ["0", "1", "2"])
+def test_orderings(hipfact_lib, ordering, monkeypatch):
+    monkeypatch.setenv("HIPFACT_ORDERING", ordering)
+    J = synth.banded_jacobian(500, 250, 10, 60, 2)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    P = _check(hipfact_lib, N, cp, ri, vx)
+    _structure_invariants(P)
+
+
+def test_wide_supernodes_are_split(hipfact_lib, monkeypatch):
+    monkeypatch.setenv("HIPFACT_WMAX", "16")
+    J = synth.uniform_jacobian(300, 200, 8, 4)  # dense Schur complement
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    P = _check(hipfact_lib, N, cp, ri, vx)
+    assert np.diff(P.sn_c0).max() <= 16
+    _structure_invariants(P)
+
+
+def test_generic_mode_spd(hipfact_lib):
+    B = sp.random(200, 200, density=0.02, random_state=0, format="csc")
+    M = (B @ B.T + sp.eye(200) * 3).tocsc()
+    L = sp.tril(M, format="csc")
+    L.sort_indices()
+    P = _check(hipfact_lib, 200, L.indptr, L.indices, L.data)
+    assert not P.saddle and P.m == 200
+    _structure_invariants(P)
+
+
+def test_generic_mode_quasidefinite(hipfact_lib):
+    # [H A^T; A -dI] with an SPD (non-identity) H: not the saddle shape -> generic engine
+    n, m = 60, 25
+    A = synth.uniform_jacobian(n, m, 5, 7)
+    H = sp.diags(np.linspace(1.0, 3.0, n)) + sp.diags(np.full(n - 1, 0.2), -1) + sp.diags(np.full(n - 1, 0.2), 1)
+    K = sp.bmat([[H, A.T], [A, -1e-2 * sp.eye(m)]], format="csc")
+    L = sp.tril(K, format="csc")
+    L.sort_indices()
+    P = _check(hipfact_lib, n + m, L.indptr, L.indices, L.data, tol=1e-7)
+    assert not P.saddle
+
+
+def test_rejects_malformed(hipfact_lib):
+    # entry above the diagonal
+    with pytest.raises(RuntimeError):
+        Plan(hipfact_lib, 2, np.array([0, 1, 3]), np.array([0, 0, 1]), np.array([1.0, 1.0, 1.0]))
+    # unsorted rows
+    with pytest.raises(RuntimeError):
+        Plan(hipfact_lib, 3, np.array([0, 3, 3, 3]), np.array([0, 2, 1]), np.array([1.0, 1.0, 1.0]))
+
+
+def test_unit_diagonal_required_for_saddle(hipfact_lib):
+    J = synth.uniform_jacobian(10, 4, 3, 0)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    vx = vx.copy()
+    vx[0] = 2.0  # (1,1) block no longer the identity
+    P = Plan(hipfact_lib, N, cp, ri, vx)
+    assert not P.saddle
+
+
+def test_config4_scale_statistics(hipfact_lib):
+    """The north-star configuration analyses in seconds and yields a short, bushy tree."""
+    J = synth.banded_jacobian(100000, 50000, 20, 200, 0)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    P = Plan(hipfact_lib, N, cp, ri, vx)
+    assert P.saddle and P.N == 150000
+    assert P.nlevels <= 40
+    assert P.nnzL < 2.0e7
+    _structure_invariants(P)

@@ -1,0 +1,357 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs (sizes the oracle finishes in seconds), the
+reference tests' known answers, edge cases, and size-independent properties at
+BASELINE.json's full sizes.
+
+Tolerances (BASELINE.md "Parity"): solutions within 1e-9 relative of the
+LAPACK-restating oracle; scaled residual <= 1e-12 after refinement; integer /
+byte work (K assembly) bit-exact.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from sleqp_amd import synth
+from util import REL_TOL, RESID_TOL, ZERO_EPS, rel_err, scaled_residual
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fact():
+    from sleqp_amd.fact import HipFact
+
+    f = HipFact(device=0)
+    yield f
+    f.free()
+
+
+def _problem(n, m, kind, frac, seed):
+    J = synth.banded_jacobian(n, m, min(12, n), min(80, n), seed) if kind == "b" else synth.uniform_jacobian(n, m, min(4, n), seed)
+    vi, ci, W = synth.working_set_all_rows(n, m, frac, seed)
+    return J, vi, ci, W
+
+
+@pytest.mark.parametrize("n,m,kind,frac", [(2, 1, "u", 0.0), (7, 3, "u", 0.3), (64, 64, "u", 0.0), (300, 150, "b", 0.1),
+                                            (1000, 500, "u", 0.0), (1500, 700, "b", 0.05)])
+@pytest.mark.parametrize("refine", [0, 1])
+def test_factor_solve_vs_oracle(fact, n, m, kind, frac, refine):
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    J, vi, ci, W = _problem(n, m, kind, frac, 3)
+    if n == m:  # square working set: add a dominant diagonal so that A_W is well conditioned
+        J = sp.csc_matrix(J + 4 * sp.eye(n))
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    fact.set_option("refine_steps", refine)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("saddle") == 1.0
+    rng = np.random.default_rng(5)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    # dense rhs
+    b = rng.standard_normal(N)
+    ref.solve_dense(b)
+    fact.solve(b)
+    z = fact.solution_raw(0, N)
+    assert rel_err(z, ref.raw_solution()) <= REL_TOL
+    if refine:
+        assert scaled_residual(K, z, b) <= RESID_TOL
+    # sparse rhs (SleqpVec), several solution() ranges per solve
+    idx = np.sort(rng.choice(N, max(1, N // 3), replace=False)).astype(np.int32)
+    val = rng.standard_normal(idx.size)
+    ref.solve_sparse(idx, val)
+    fact.solve(SleqpVec(N, idx, val))
+    want = ref.raw_solution()
+    assert rel_err(fact.solution_raw(0, n), want[:n]) <= REL_TOL
+    assert rel_err(fact.solution_raw(n, N), want[n:]) <= REL_TOL
+    # packed output identical in structure to sleqp_vec_set_from_raw on the oracle's buffer
+    sv = fact.solution(0, N, ZERO_EPS)
+    oi, od = ref.solution(0, N, ZERO_EPS)
+    assert rel_err(sv.to_raw(), oracle.vec_to_raw(N, oi, od)) <= REL_TOL
+
+
+def test_reference_known_answers_on_device(fact):
+    """constrained_newton_test.c:204-275, unconstrained_newton_test.c:67-205 and
+    dual_estimation_test.c:15-103 known answers, reproduced through the device backend."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    aug = StandardAugJac(2, fact)
+    aug.set_iterate(SleqpMat(1, 2, [0, 0, 1], [0], [1.0]), [-1, -1], [0])
+    p = aug.project_nullspace(SleqpVec(2, [0, 1], [2.0, 4.0]))
+    assert p.indices.tolist() == [0] and abs(p.data[0] - 2.0) < 1e-8
+    # Newton step of the strictly convex model = -P g / 2 = (-1, 0)
+    assert np.allclose(-0.5 * p.to_raw(), [-1.0, 0.0], atol=1e-8)
+    # empty working set: projection is the identity, step (-1, -2)
+    aug.set_iterate(SleqpMat(0, 2, [0, 0, 0], [], []), [-1, -1], [])
+    p = aug.project_nullspace(SleqpVec(2, [0, 1], [2.0, 4.0]))
+    assert np.allclose(-0.5 * p.to_raw(), [-1.0, -2.0], atol=1e-8)
+    # both bounds active: LSQ duals of -grad = (-2, -4)
+    aug.set_iterate(SleqpMat(0, 2, [0, 0, 0], [], []), [0, 1], [])
+    d = aug.solve_lsq(SleqpVec(2, [0, 1], [-2.0, -4.0]))
+    assert d.indices.tolist() == [0, 1] and np.allclose(d.data, [-2.0, -4.0], atol=1e-8)
+    # SURVEY §8c reference run: A = [1 2], P (3, 1) = (2, -1)
+    aug.set_iterate(SleqpMat(1, 2, [0, 1, 2], [0, 0], [1.0, 2.0]), [-1, -1], [0])
+    p = aug.project_nullspace(SleqpVec(2, [0, 1], [3.0, 1.0]))
+    assert np.allclose(p.to_raw(), [2.0, -1.0], atol=1e-13)
+
+
+def test_steihaug_cg_on_device_projection(fact):
+    """The reference's projected CG (tr/steihaug_solver.c) driven by device projections gives the
+    same step as the oracle's restatement driven by the LAPACK-restating projections."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 120, 50
+    J, vi, ci, W = _problem(n, m, "u", 0.05, 9)
+    rng = np.random.default_rng(2)
+    B = sp.random(n, n, density=0.03, random_state=1)
+    H = (B @ B.T + sp.eye(n)).tocsc()
+    HL = sp.tril(H, format="csc")
+    HL.sort_indices()
+    g = rng.standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    want, its = ref.steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=0.7)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+
+    def P(v):
+        return aug.project_nullspace(SleqpVec.from_raw(v)).to_raw()
+
+    # steihaug_solver.c:218-496 with dense vectors
+    z, r = np.zeros(n), g.copy()
+    gg = P(r)
+    d = -gg
+    rg = r @ gg
+    step = np.zeros(n)
+    for it in range(100):
+        if abs(rg) < 1e-16:
+            step = z
+            break
+        Bd = H @ d
+        dBd = d @ Bd
+        alpha = rg / dBd
+        zn = z + alpha * d
+        if zn @ zn >= 0.7 ** 2:
+            pd, dd, pp = z @ d, d @ d, z @ z
+            step = z + (-pd + np.sqrt(pd * pd - dd * (pp - 0.49))) / dd * d
+            break
+        z = zn
+        r = r + alpha * Bd
+        gg = P(r)
+        beta = 1.0 / rg
+        rg = r @ gg
+        beta *= rg
+        d = -gg + beta * d
+    assert rel_err(step, want) <= 1e-8
+
+
+def test_pattern_cache_and_refactor(fact):
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, W = _problem(400, 200, "b", 0.0, 1)
+    N, kc, kr, kd = oracle.fill_aug_jac(400, 200, J.indptr, J.indices, J.data, vi, ci)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("analyses") == 1
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(N)
+    for _ in range(3):  # same pattern, new values: numeric-only refactorisation
+        kd2 = kd.copy()
+        off = kr != np.repeat(np.arange(N), np.diff(kc))
+        kd2[off] = rng.standard_normal(int(off.sum()))
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd2))
+        ref = oracle.OracleFact(N, kc, kr, kd2)
+        ref.solve_dense(b)
+        fact.solve(b)
+        assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL
+    assert fact.info("analyses") == 1 and fact.info("cache_hits") == 3
+    # N and nnz change between calls (standard_aug_jac.c: working set changes)
+    J2, vi2, ci2, _ = _problem(300, 100, "u", 0.1, 2)
+    N2, c2, r2, d2 = oracle.fill_aug_jac(300, 100, J2.indptr, J2.indices, J2.data, vi2, ci2)
+    fact.set_matrix(SleqpMat(N2, N2, c2, r2, d2))
+    assert fact.info("analyses") == 2
+    b2 = rng.standard_normal(N2)
+    ref = oracle.OracleFact(N2, c2, r2, d2)
+    ref.solve_dense(b2)
+    fact.solve(b2)
+    assert rel_err(fact.solution_raw(0, N2), ref.raw_solution()) <= REL_TOL
+
+
+def test_error_behaviour(fact):
+    from sleqp_amd import HipfactError
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    # solve before set_matrix (call protocol)
+    with pytest.raises(HipfactError) as e:
+        fact.solve(np.zeros(0))
+    assert e.value.code == -5
+    # rank-deficient working set (duplicate rows): zero pivot -> HIPFACT_ESINGULAR,
+    # like "Failed to factorize using LAPACK" (fact_lapack.c:117-120)
+    N, kc, kr, kd = oracle.fill_aug_jac(2, 2, [0, 2, 4], [0, 1, 0, 1], [1.0, 1.0, 2.0, 2.0], [-1, -1], [0, 1])
+    with pytest.raises(HipfactError) as e:
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert e.value.code == -3
+    with pytest.raises(ZeroDivisionError):
+        oracle.OracleFact(N, kc, kr, kd)
+    # malformed matrix
+    with pytest.raises(HipfactError) as e:
+        fact.set_matrix(SleqpMat(2, 2, [0, 1, 3], [0, 0, 1], [1.0, 1.0, 1.0]))
+    assert e.value.code == -1
+    # rhs of the wrong dimension
+    J, vi, ci, _ = _problem(20, 8, "u", 0.0, 0)
+    N, kc, kr, kd = oracle.fill_aug_jac(20, 8, J.indptr, J.indices, J.data, vi, ci)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    with pytest.raises(HipfactError):
+        fact.solve(SleqpVec(N + 1, [0], [1.0]))
+    with pytest.raises(HipfactError):
+        fact.solution_raw(0, N)  # no solve yet
+    fact.solve(SleqpVec(N, [], []))  # empty rhs
+    assert np.array_equal(fact.solution_raw(0, N), np.zeros(N))
+    with pytest.raises(HipfactError):
+        fact.solution_raw(0, N + 1)
+
+
+def test_generic_mode_on_device(fact):
+    from sleqp_amd.sparse import SleqpMat
+
+    # SPD (what the reduced AugJac hands to PSD backends) and quasi-definite inputs
+    B = sp.random(600, 600, density=0.01, random_state=0, format="csc")
+    M = (B @ B.T + sp.eye(600) * 3).tocsc()
+    n, m = 80, 30
+    A = synth.uniform_jacobian(n, m, 5, 7)
+    Hq = sp.diags(np.linspace(1.0, 3.0, n)) + sp.diags(np.full(n - 1, 0.2), -1) + sp.diags(np.full(n - 1, 0.2), 1)
+    Q = sp.bmat([[Hq, A.T], [A, -1e-2 * sp.eye(m)]], format="csc")
+    for mat in (M, Q):
+        L = sp.tril(mat, format="csc")
+        L.sort_indices()
+        N = mat.shape[0]
+        fact.set_matrix(SleqpMat(N, N, L.indptr, L.indices, L.data))
+        assert fact.info("saddle") == 0.0
+        b = np.random.default_rng(1).standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        ref = oracle.OracleFact(N, L.indptr, L.indices, L.data)
+        ref.solve_dense(b)
+        assert rel_err(z, ref.raw_solution()) <= 1e-8
+        assert scaled_residual(mat, z, b) <= 1e-12
+
+
+def test_condition_estimate(fact):
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(200, 80, "u", 0.0, 0)
+    N, kc, kr, kd = oracle.fill_aug_jac(200, 80, J.indptr, J.indices, J.data, vi, ci)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    c = fact.cond()
+    assert np.isfinite(c) and c >= 1.0
+
+
+def test_spmv_kernels(fact):
+    from sleqp_amd.fact import SpMat
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    rng = np.random.default_rng(0)
+    for (r, c, dens) in [(1, 1, 1.0), (50, 80, 0.05), (400, 900, 0.01), (300, 300, 0.3), (2000, 10, 0.5)]:
+        M = sp.random(r, c, density=dens, random_state=1, format="csc")
+        M.sort_indices()
+        S = SpMat(fact, SleqpMat.from_scipy(M))
+        xi = np.sort(rng.choice(c, max(1, c // 2), replace=False)).astype(np.int32)
+        xd = rng.standard_normal(xi.size)
+        want = oracle.mat_mult_vec(r, c, M.indptr, M.indices, M.data, xi, xd)
+        assert rel_err(S.mult_vec(SleqpVec(c, xi, xd)), want) <= 1e-14
+        yi = np.sort(rng.choice(r, max(1, r // 2), replace=False)).astype(np.int32)
+        yd = rng.standard_normal(yi.size)
+        ti, td = oracle.mat_mult_vec_trans(r, c, M.indptr, M.indices, M.data, yi, yd, 0.0)
+        got = S.mult_vec_trans(SleqpVec(r, yi, yd), eps=0.0)
+        assert rel_err(got.to_raw(), oracle.vec_to_raw(c, ti, td)) <= 1e-14
+        S.free()
+    # symmetric product from the lower triangle (mex_hess.c:85-139)
+    H = sp.random(300, 300, density=0.05, random_state=2)
+    H = (H + H.T + sp.eye(300)).tocsc()
+    HL = sp.tril(H, format="csc")
+    HL.sort_indices()
+    S = SpMat(fact, SleqpMat.from_scipy(HL))
+    d = rng.standard_normal(300)
+    assert rel_err(S.mult_vec_sym(d), oracle.hess_prod_lower(300, HL.indptr, HL.indices, HL.data, d)) <= 1e-14
+    # empty matrix
+    E = SpMat(fact, SleqpMat(3, 4))
+    assert np.array_equal(E.mult_vec(np.ones(4)), np.zeros(3))
+
+
+def test_assembly_bit_exact(fact):
+    from sleqp_amd.sparse import SleqpMat
+
+    rng = np.random.default_rng(4)
+    for n, m in [(1, 0), (5, 3), (500, 300), (5000, 2000)]:
+        J = synth.uniform_jacobian(n, m, min(4, n), 2) if m > 0 else sp.csc_matrix((0, n))
+        vi = np.full(n, -1, dtype=np.int32)
+        av = np.sort(rng.choice(n, n // 10, replace=False))
+        vi[av] = np.arange(av.size)
+        ci = np.full(m, -1, dtype=np.int32)
+        ac = np.sort(rng.choice(m, (2 * m) // 3, replace=False)) if m > 0 else np.zeros(0, int)
+        ci[ac] = av.size + np.arange(ac.size)
+        W = av.size + ac.size
+        K = fact.assemble_kkt(SleqpMat.from_scipy(J), vi, ci, W)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        assert K.num_cols == N
+        assert np.array_equal(K.cols, kc) and np.array_equal(K.rows, kr) and np.array_equal(K.data, kd)
+
+
+def test_determinism(fact):
+    """Same inputs -> bitwise identical solution (fixed summation order, no atomics)."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(2000, 1000, "b", 0.05, 6)
+    N, kc, kr, kd = oracle.fill_aug_jac(2000, 1000, J.indptr, J.indices, J.data, vi, ci)
+    b = np.random.default_rng(0).standard_normal(N)
+    outs = []
+    for _ in range(3):
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("workload", ["banded_n1e5_m5e4", "uniform_n1e4_m5e3"])
+def test_full_size_properties(fact, workload):
+    """BASELINE.json configs[3] / configs[2] at full size: properties that do not need the dense oracle."""
+    from bench import make_problem
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    J, N, cp, ri, vx, b = make_problem(workload, 0)
+    n = J.shape[1]
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    # (1) residual of a dense solve
+    fact.solve(b)
+    z = fact.solution_raw(0, N)
+    assert scaled_residual(K, z, b) <= RESID_TOL
+    # (2) agreement with the oracle's sparse LDL^T (CPU baseline, BASELINE.md: <= 1e-8)
+    if workload.startswith("banded"):
+        x = oracle.OracleLdl(N, cp, ri, vx).solve(b)
+        assert rel_err(z, x) <= 1e-8
+    # (3) linearity
+    b2 = np.random.default_rng(9).standard_normal(N)
+    fact.solve(b2)
+    z2 = fact.solution_raw(0, N)
+    fact.solve(2.0 * b - 3.0 * b2)
+    assert rel_err(fact.solution_raw(0, N), 2.0 * z - 3.0 * z2) <= 1e-9
+    # (4) projection: A P g = 0, P idempotent, (g - P g) in range(A^T)
+    g = np.zeros(N)
+    g[:n] = np.random.default_rng(3).standard_normal(n)
+    fact.solve(SleqpVec.from_raw(g))
+    Pg = fact.solution_raw(0, n)
+    A = J.tocsr()
+    assert np.abs(A @ Pg).max() <= 1e-9 * np.abs(A).sum(axis=1).max() * np.abs(g).max()
+    g2 = np.zeros(N)
+    g2[:n] = Pg
+    fact.solve(SleqpVec.from_raw(g2))
+    assert rel_err(fact.solution_raw(0, n), Pg) <= 1e-9
+    # (5) min-norm solve satisfies A x = rhs
+    rhs = np.zeros(N)
+    rhs[n:] = np.random.default_rng(4).standard_normal(N - n)
+    fact.solve(SleqpVec.from_raw(rhs))
+    x = fact.solution_raw(0, n)
+    assert np.abs(A @ x - rhs[n:]).max() <= 1e-9 * max(1.0, np.abs(x).max()) * np.abs(A).sum(axis=1).max()

@@ -1,0 +1,34 @@
+"""Repository rules: the product never touches oracle/ or the reference tree."""
+import os
+import re
+
+from conftest import ROOT
+
+PRODUCT_DIRS = ["sleqp_amd", "shim", "include"]
+
+
+def _files(d):
+    for base, _, names in os.walk(os.path.join(ROOT, d)):
+        for n in names:
+            if n.endswith((".py", ".c", ".h", ".cpp", ".hip", ".cmake", "Makefile")):
+                yield os.path.join(base, n)
+
+
+def test_product_does_not_use_oracle_or_reference():
+    bad = []
+    for d in PRODUCT_DIRS:
+        for f in _files(d):
+            text = open(f, errors="replace").read()
+            code = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith(("#", "//", "*", "/*", '"""')))
+            if re.search(r"(liboracle|import oracle|from oracle|oracle/|/root/reference)", code):
+                # documentation strings may name the oracle as the place where parity is defined
+                hits = [l for l in code.splitlines() if re.search(r"(liboracle|import oracle|from oracle|/root/reference)", l)]
+                if hits:
+                    bad.append((f, hits[:2]))
+    assert not bad, bad
+
+
+def test_required_layout():
+    for p in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/hipfact.h", "oracle/kkt_oracle.c",
+              "tests/golden/kkt_cases.npz", "tests/golden/make_golden.py", "shim/fact_hipfact.c", "profiles"]:
+        assert os.path.exists(os.path.join(ROOT, p)), p
