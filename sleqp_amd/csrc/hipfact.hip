@@ -103,6 +103,7 @@ struct hipfact_handle {
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
   int refine_steps = 1;
+  int debug_phases = 15;  // timing-only phase mask of k_factor_level (15 = everything)
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
@@ -262,8 +263,8 @@ static int upload_plan(hipfact_handle* h) {
       mu = std::max(mu, r - w);
     }
     const size_t wp = (size_t)((mw + 15) & ~15);
-    li.lds_factor = (wp * wp + wp + 2048) * sizeof(double);
-    li.lds_fwd = ((size_t)mr + mw + 2) * sizeof(double);
+    li.lds_factor = (wp * (wp + 1) + wp + 16 * (wp + 1)) * sizeof(double);
+    li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
     li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
   }
@@ -324,7 +325,7 @@ static int factor_async(hipfact_handle* h) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(),
-                       h->d_rel.as<int>(), h->d_child.as<int>(), h->d_info.as<int>());
+                       h->d_rel.as<int>(), h->d_child.as<int>(), h->d_info.as<int>(), h->debug_phases);
   }
   HCHECK(h, hipGetLastError());
   h->num_factor++;
@@ -351,13 +352,13 @@ static void solve_m_async(hipfact_handle* h) {
   const Plan& P = h->plan;
   for (int l = 0; l < P.nlevels; ++l) {
     const LevelInfo& li = h->levels[l];
-    LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(FB), li.lds_fwd, h->d_sn.as<SnDesc>(),
+    LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(SB), li.lds_fwd, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(),
                        h->d_child.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>());
   }
   for (int l = P.nlevels - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];
-    LAUNCH(PC_BWD, k_bwd_level, dim3(li.count), dim3(FB), li.lds_bwd, h->d_sn.as<SnDesc>(),
+    LAUNCH(PC_BWD, k_bwd_level, dim3(li.count), dim3(SB), li.lds_bwd, h->d_sn.as<SnDesc>(),
                        h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(),
                        h->d_y.as<double>());
   }
@@ -901,6 +902,10 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   if (!h || !name) return HIPFACT_EINVAL;
   if (!strcmp(name, "refine_steps")) {
     h->refine_steps = std::max(0, (int)value);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "debug_phases")) {
+    h->debug_phases = (int)value;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "profile")) {  // event-time every kernel class; value < 0 resets the counters

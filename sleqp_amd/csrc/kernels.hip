@@ -62,33 +62,52 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 }
 
 // ---------------------------------------------------------------------------
-// Front factorisation: one workgroup per front, all fronts of one
-// elimination-tree level per launch.
+// Front factorisation: one workgroup (4 waves) per front, all fronts of one
+// elimination-tree level per launch.  Every dense phase runs on the fp64
+// matrix cores (v_mfma_f64_16x16x4_f64, verified lane layout: A[l&15][l>>4],
+// B[l>>4][l&15], D[(l>>4)+4q][l&15]).
 //
 //   A0  zero the update matrix U_s
 //   A1  extend-add the children's update matrices (relative indices)
-//   B   dense LDL^T of the w x w pivot block in LDS, then its inverse
-//       (recursive doubling) so that the solves are pure GEMVs
-//   C   L21 = P21 * inv(L11)^T * D^-1   (row-parallel)
-//   D   U_s -= L21 D L21^T              (64 x 64 tiles through LDS)
+//   B   blocked LDL^T (nb = 16) of the w x w pivot block in LDS:
+//         S1  16x16 diagonal block: LDL^T and its inverse in registers of one
+//             wave (cross-lane shuffles, no memory traffic)
+//         S2  block column  L_Ik = A_Ik inv(L_kk)^T D^-1          (MFMA)
+//         S3  trailing update A_IJ -= L_Ik D L_Jk^T                (MFMA)
+//       then the inverse of the unit lower factor by recursive doubling with
+//       MFMA products, so that the solves are pure GEMVs
+//   C   L21 = P21 inv(L11)^T D^-1, operands streamed from the panel  (MFMA)
+//   D   U_s -= L21 D L21^T, 32x32 blocks per wave, operands streamed (MFMA)
+//
+// LDS: A (wp x lda, lda = wp + 1: both the row-fragment and the transposed
+// fragment reads stay <= 2-way bank conflicted), the pivots, a 16-column panel Y.
 // ---------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
 __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ sn,
                                                      const int* __restrict__ level_sn, double* __restrict__ L,
                                                      double* __restrict__ U, const int* __restrict__ rel,
-                                                     const int* __restrict__ child_idx, int* __restrict__ info) {
+                                                     const int* __restrict__ child_idx, int* __restrict__ info,
+                                                     int phases) {
+  // phases: bit mask A(1) B(2) C(4) D(8); anything but 15 is a timing-only build
+  // of the same kernel (results are then wrong by construction).
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
   const SnDesc S = sn[level_sn[blockIdx.x]];
   const int w = S.w, r = S.r, u = r - w;
   double* __restrict__ P = L + S.Loff;
   double* __restrict__ Us = U + S.Uoff;
   const int wp = (w + 15) & ~15;
-  double* A = lds;             // wp x wp, ld = wp
-  double* dd = A + wp * wp;    // wp pivots
-  double* TA = dd + wp;        // 16 x 64
-  double* TB = TA + 1024;      // 16 x 64
+  const int nbk = wp >> 4;
+  const int lda = wp + 1;
+  double* A = lds;            // wp x lda
+  double* dd = A + wp * lda;  // wp pivots
+  double* Yp = dd + wp;       // wp x 16 panel (L * D of the current block column), ld = lda
 
   // ---- A0
+  if (phases & 1) {
   for (long long i = tid; i < (long long)u * u; i += FB) Us[i] = 0.0;
   __syncthreads();
   // ---- A1
@@ -110,213 +129,285 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     }
     __syncthreads();
   }
+  }
+  if (!(phases & 2)) return;
 
   // ---- B: pivot block into LDS (lower triangle, identity padding)
   for (int k = wave; k < wp; k += 4)
     for (int i = lane; i < wp; i += 64) {
       double v = (i == k) ? 1.0 : 0.0;
       if (i < w && k < w) v = (i >= k) ? P[i + (long long)k * r] : 0.0;
-      A[i + k * wp] = v;
+      A[i + k * lda] = v;
     }
   __syncthreads();
-  {
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int k = 0; k < w; ++k) {
-      double d = A[k + k * wp];
-      if (d == 0.0 || !(fabs(d) <= 1.7e308)) {  // exactly singular or non-finite
-        if (tid == 0) atomicAdd(&info[INFO_ZERO_PIVOT], 1);
-        d = 1.0;
+
+  for (int kb = 0; kb < nbk; ++kb) {
+    const int k0 = kb << 4;
+    // S1: wave 0 factors the diagonal block and inverts its unit lower factor.
+    // lane (i = li, q = lk) owns A[i][4q..4q+3] and X[i][4q..4q+3].
+    if (wave == 0) {
+      double a[4], x[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[c] = A[(k0 + li) + (k0 + 4 * lk + c) * lda];
+        x[c] = (li == 4 * lk + c) ? 1.0 : 0.0;
       }
-      if (tid == 0) {
-        dd[k] = d;
-        if (d < 0.0) atomicAdd(&info[INFO_NEG_PIVOT], 1);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int qk = k >> 2, kr = k & 3;
+        const double ck_i = __shfl(a[kr], (qk << 4) | li, 64);  // A[i][k]
+        double d = __shfl(a[kr], (qk << 4) | k, 64);            // A[k][k]
+        if (d == 0.0 || !(fabs(d) <= 1.7e308)) {
+          if (lane == 0) atomicAdd(&info[INFO_ZERO_PIVOT], 1);
+          d = 1.0;
+        }
+        if (lane == 0) {
+          dd[k0 + k] = d;
+          if (d < 0.0) atomicAdd(&info[INFO_NEG_PIVOT], 1);
+        }
+        const double l_ik = (li > k) ? ck_i / d : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double xk = __shfl(x[c], (lk << 4) | k, 64);  // X[k][4q+c]
+          x[c] -= l_ik * xk;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = 4 * lk + c;
+          const double ck_j = __shfl(a[kr], (qk << 4) | j, 64);  // A[j][k]
+          if (j > k) a[c] -= l_ik * ck_j;
+        }
       }
-      const double dinv = 1.0 / d;
-      for (int j = k + 1 + ty; j < w; j += 16) {
-        const double ajk = A[j + k * wp] * dinv;
-        for (int i = j + tx; i < w; i += 16) A[i + j * wp] -= A[i + k * wp] * ajk;
-      }
-      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[(k0 + li) + (k0 + 4 * lk + c) * lda] = x[c];
     }
-    if (tid >= w && tid < wp) dd[tid] = 1.0;
     __syncthreads();
-    // unit lower L11 (strict part scaled by 1/d), unit diagonal
-    for (int k = wave; k < w; k += 4) {
-      const double dinv = 1.0 / dd[k];
-      for (int i = k + lane; i < w; i += 64) A[i + k * wp] = (i == k) ? 1.0 : A[i + k * wp] * dinv;
+    // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
+    for (int I = kb + 1 + wave; I < nbk; I += 4) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double av = A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
+        const double bv = A[(k0 + li) + (k0 + 4 * s + lk) * lda];
+        acc = MFMA_F64(av, bv, acc);
+      }
+      const double dinv = 1.0 / dd[k0 + li];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * I + lk + 4 * q;
+        Yp[row + li * lda] = acc[q];
+        A[row + (k0 + li) * lda] = acc[q] * dinv;
+      }
+    }
+    __syncthreads();
+    // S3: trailing update of the lower block triangle.
+    {
+      const int T = nbk - kb - 1;
+      const int ntiles = T * (T + 1) / 2;
+      for (int t = wave; t < ntiles; t += 4) {
+        int J = 0, rem = t;
+        while (rem >= T - J) {
+          rem -= T - J;
+          ++J;
+        }
+        const int I = kb + 1 + J + rem;
+        J += kb + 1;
+        d4_t acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = A[(16 * I + lk + 4 * q) + (16 * J + li) * lda];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double av = -A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
+          const double bv = Yp[(16 * J + li) + (4 * s + lk) * lda];
+          acc = MFMA_F64(av, bv, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[(16 * I + lk + 4 * q) + (16 * J + li) * lda] = acc[q];
+      }
     }
     __syncthreads();
   }
-  // ---- B2: inverse of the unit lower triangular block, in place.
-  {
-    // base: 16 x 16 diagonal blocks, one thread per column, staged in registers
-    const int nb = wp >> 4;
-    double x[16];
-    const int q = tid >> 4, c = tid & 15;
-    if (tid < nb * 16) {
-      const double* Bq = A + (q * 16) + (q * 16) * wp;
+
+  // ---- B2: inverse of the unit lower block factor by recursive doubling.
+  // A holds inv(L_kk) in the diagonal blocks and L_IJ below.  For the block
+  // [X11 0; B X22] the off-diagonal block of the inverse is -X22 B X11; one wave
+  // computes one 16-column strip of it in registers (the accumulator tiles of the
+  // first product are the B operands of the second), then all strips are stored.
+  for (int h = 16; h < wp; h <<= 1) {
+    const int ht = h >> 4;
+    const int ntask = (wp + 2 * h - 1) / (2 * h);
+    const int units = ntask * ht;
+    const int task = wave / ht, tc = wave - task * ht;
+    const int b = task * 2 * h;
+    const int h2 = min(h, wp - b - h);
+    const bool active = (wave < units) && (h2 > 0);
+    const int h2t = active ? (h2 >> 4) : 0;
+    d4_t Tt[4], R[4];
+    if (active) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double s = (i == c) ? 1.0 : 0.0;
+      for (int ti = 0; ti < 4; ++ti) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (ti < h2t) {
+          for (int tt = tc; tt < ht; ++tt)
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          if (t < i) s -= Bq[i + t * wp] * x[t];
-        x[i] = s;
+            for (int s = 0; s < 4; ++s) {
+              const double av = A[(b + h + 16 * ti + li) + (b + 16 * tt + 4 * s + lk) * lda];
+              const double bv = A[(b + 16 * tt + 4 * s + lk) + (b + 16 * tc + li) * lda];
+              acc = MFMA_F64(av, bv, acc);
+            }
+        }
+        Tt[ti] = acc;
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (ti < h2t) {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+            if (tt <= ti) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                const double av = A[(b + h + 16 * ti + li) + (b + h + 16 * tt + 4 * s + lk) * lda];
+                acc = MFMA_F64(av, Tt[tt][s], acc);
+              }
+            }
+        }
+        R[ti] = acc;
       }
     }
     __syncthreads();
-    if (tid < nb * 16) {
-      double* Bq = A + (q * 16) + (q * 16) * wp;
+    if (active) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Bq[i + c * wp] = x[i];
+      for (int ti = 0; ti < 4; ++ti)
+        if (ti < h2t) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[(b + h + 16 * ti + lk + 4 * q) + (b + 16 * tc + li) * lda] = -R[ti][q];
+        }
     }
     __syncthreads();
-    // doubling: inv([X11 0; B X22]) has off-diagonal block -X22 * B * X11
-    for (int h = 16; h < wp; h <<= 1) {
-      const int hs = 31 - __clz(h);  // log2(h)
-      const int ntask = (wp + 2 * h - 1) / (2 * h);
-      const int total = ntask << (2 * hs);
-      double acc[16];
-      // step 1: B := B * X11
-#pragma unroll
-      for (int qq = 0; qq < 16; ++qq) {
-        acc[qq] = 0.0;
-        const int e = tid + qq * FB;
-        if (e < total) {
-          const int task = e >> (2 * hs), rem = e & ((1 << (2 * hs)) - 1);
-          const int i = rem & (h - 1), cc = rem >> hs;
-          const int b = task * 2 * h;
-          const int h2 = min(h, wp - b - h);
-          if (i < h2) {
-            const double* Brow = A + (b + h + i) + b * wp;
-            const double* X = A + b + (b + cc) * wp;
-            double s = 0.0;
-            for (int t = cc; t < h; ++t) s += Brow[t * wp] * X[t];
-            acc[qq] = s;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int qq = 0; qq < 16; ++qq) {
-        const int e = tid + qq * FB;
-        if (e < total) {
-          const int task = e >> (2 * hs), rem = e & ((1 << (2 * hs)) - 1);
-          const int i = rem & (h - 1), cc = rem >> hs;
-          const int b = task * 2 * h;
-          const int h2 = min(h, wp - b - h);
-          if (i < h2) A[(b + h + i) + (b + cc) * wp] = acc[qq];
-        }
-      }
-      __syncthreads();
-      // step 2: B := -X22 * B
-#pragma unroll
-      for (int qq = 0; qq < 16; ++qq) {
-        acc[qq] = 0.0;
-        const int e = tid + qq * FB;
-        if (e < total) {
-          const int task = e >> (2 * hs), rem = e & ((1 << (2 * hs)) - 1);
-          const int i = rem & (h - 1), cc = rem >> hs;
-          const int b = task * 2 * h;
-          const int h2 = min(h, wp - b - h);
-          if (i < h2) {
-            const double* X22row = A + (b + h + i) + (b + h) * wp;  // X22[i,t] = X22row[t*wp]
-            const double* Bcol = A + (b + h) + (b + cc) * wp;       // B[t,cc] = Bcol[t]
-            double s = 0.0;
-            for (int t = 0; t <= i; ++t) s += X22row[t * wp] * Bcol[t];
-            acc[qq] = -s;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int qq = 0; qq < 16; ++qq) {
-        const int e = tid + qq * FB;
-        if (e < total) {
-          const int task = e >> (2 * hs), rem = e & ((1 << (2 * hs)) - 1);
-          const int i = rem & (h - 1), cc = rem >> hs;
-          const int b = task * 2 * h;
-          const int h2 = min(h, wp - b - h);
-          if (i < h2) A[(b + h + i) + (b + cc) * wp] = acc[qq];
-        }
-      }
-      __syncthreads();
-    }
   }
   // store inv(L11) (strict lower) and the pivots (diagonal) back to the panel
   for (int k = wave; k < w; k += 4)
-    for (int i = k + lane; i < w; i += 64) P[i + (long long)k * r] = (i == k) ? dd[k] : A[i + k * wp];
+    for (int i = k + lane; i < w; i += 64) P[i + (long long)k * r] = (i == k) ? dd[k] : A[i + k * lda];
 
-  // ---- C: L21 = P21 * X^T * D^-1, X = inv(L11); one thread per row, in place,
-  // column chunks in descending order (a chunk only reads columns <= its own).
-  for (int i = w + tid; i < r; i += FB) {
-    double* Prow = P + i;
-    for (int c0 = ((w - 1) >> 3) << 3; c0 >= 0; c0 -= 8) {
-      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int cmax = min(c0 + 8, w) - 1;
-      const double* Xc = A + c0;
-      for (int t = 0; t <= cmax; ++t) {
-        const double p = Prow[(long long)t * r];
+  if (!(phases & 4)) return;
+  // ---- C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel rows
+  // at a time: the B operand streams from the panel (16 consecutive rows per
+  // k-step), the A operand is X from LDS; results are stored row-contiguous.
+  for (int R0 = w + 16 * wave; R0 < r; R0 += 64) {
+    const bool rok = (R0 + li) < r;
+    const double* __restrict__ Prow = P + R0 + li;
+    d4_t acc[8];
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) acc[qq] += p * Xc[qq + t * wp];
+    for (int ct = 0; ct < 8; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double pv[4], pn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int col = 4 * s + lk;
+      pv[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
+    }
+    for (int tt = 0; tt < nbk; ++tt) {
+      if (tt + 1 < nbk) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int col = 16 * (tt + 1) + 4 * s + lk;
+          pn[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
+        }
       }
 #pragma unroll
-      for (int qq = 0; qq < 8; ++qq)
-        if (c0 + qq < w) Prow[(long long)(c0 + qq) * r] = acc[qq] / dd[c0 + qq];
+      for (int ct = 0; ct < 8; ++ct)
+        if (ct >= tt && ct < nbk) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
+            acc[ct] = MFMA_F64(xv, pv[s], acc[ct]);
+          }
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pv[s] = pn[s];
+    }
+    if (rok) {
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct)
+        if (ct < nbk) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = 16 * ct + lk + 4 * q;
+            if (col < w) P[(R0 + li) + (long long)col * r] = acc[ct][q] / dd[col];
+          }
+        }
     }
   }
   __syncthreads();
 
-  // ---- D: U_s -= L21 D L21^T
-  {
-    const int tx = tid & 15, ty = tid >> 4;
+  // ---- D: U_s -= L21 D L21^T.  One 32 x 32 block of the lower triangle per
+  // wave and iteration; computed transposed (rows of the accumulator = j) so that
+  // the read-modify-write of U is contiguous in i.
+  if (u > 0 && (phases & 8)) {
     const double* __restrict__ P21 = P + w;
-    for (int J0 = 0; J0 < u; J0 += 64)
-      for (int I0 = J0; I0 < u; I0 += 64) {
-        double acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-        for (int k0 = 0; k0 < w; k0 += 16) {
-          __syncthreads();
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int e = tid + qq * FB;
-            const int i = e & 63, kk = e >> 6;
-            const int k = k0 + kk;
-            double va = 0.0, vb = 0.0;
-            if (k < w) {
-              if (I0 + i < u) va = P21[(I0 + i) + (long long)k * r];
-              if (J0 + i < u) vb = P21[(J0 + i) + (long long)k * r] * dd[k];
-            }
-            TA[e] = va;
-            TB[e] = vb;
-          }
-          __syncthreads();
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = TA[kk * 64 + tx + 16 * a];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = TB[kk * 64 + ty + 16 * b];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int j = J0 + ty + 16 * b;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int i = I0 + tx + 16 * a;
-            if (i < u && j < u && i >= j) Us[i + (long long)j * u] -= acc[a][b];
-          }
-        }
+    const int nb32 = (u + 31) >> 5;
+    const long long nblk = (long long)nb32 * (nb32 + 1) / 2;
+    int J = 0;
+    long long base = 0;  // first block index of block column J
+    for (long long blk = wave; blk < nblk; blk += 4) {
+      while (blk - base >= nb32 - J) {
+        base += nb32 - J;
+        ++J;
       }
+      const int I = J + (int)(blk - base);
+      const int i0 = 32 * I, j0 = 32 * J;
+      d4_t acc[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
+      const bool jok0 = (j0 + li) < u, jok1 = (j0 + 16 + li) < u;
+      const bool iok0 = (i0 + li) < u, iok1 = (i0 + 16 + li) < u;
+      const double* __restrict__ Pj = P21 + j0 + li;
+      const double* __restrict__ Pi = P21 + i0 + li;
+      double aj0, aj1, bi0, bi1;
+      {
+        const bool kok = lk < w;
+        const long long off = (long long)lk * r;
+        const double dk = kok ? dd[lk] : 0.0;
+        aj0 = (kok && jok0) ? Pj[off] * dk : 0.0;
+        aj1 = (kok && jok1) ? Pj[off + 16] * dk : 0.0;
+        bi0 = (kok && iok0) ? Pi[off] : 0.0;
+        bi1 = (kok && iok1) ? Pi[off + 16] : 0.0;
+      }
+      for (int k0 = 0; k0 < w; k0 += 4) {
+        double naj0 = 0.0, naj1 = 0.0, nbi0 = 0.0, nbi1 = 0.0;
+        const int kn = k0 + 4 + lk;
+        if (kn < w) {
+          const long long off = (long long)kn * r;
+          const double dk = dd[kn];
+          if (jok0) naj0 = Pj[off] * dk;
+          if (jok1) naj1 = Pj[off + 16] * dk;
+          if (iok0) nbi0 = Pi[off];
+          if (iok1) nbi1 = Pi[off + 16];
+        }
+        acc[0][0] = MFMA_F64(aj0, bi0, acc[0][0]);
+        acc[0][1] = MFMA_F64(aj0, bi1, acc[0][1]);
+        acc[1][0] = MFMA_F64(aj1, bi0, acc[1][0]);
+        acc[1][1] = MFMA_F64(aj1, bi1, acc[1][1]);
+        aj0 = naj0;
+        aj1 = naj1;
+        bi0 = nbi0;
+        bi1 = nbi1;
+      }
+      // acc[x][y][q] = update of U(i = i0 + 16 y + li, j = j0 + 16 x + lk + 4 q)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          const int i = i0 + 16 * y + li;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = j0 + 16 * x + lk + 4 * q;
+            if (i < u && j < u && i >= j) Us[i + (long long)j * u] -= acc[x][y][q];
+          }
+        }
+    }
   }
 }
 
@@ -326,46 +417,111 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
 // ancestors travels as update vectors (deterministic, no atomics).  Backward:
 // parents -> children, gathers the ancestors' solution.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+constexpr int SB = 1024;  // threads per block of the solve kernels (16 waves hide the panel-read latency)
+
+__global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rel,
                                                   const int* __restrict__ child_idx, double* __restrict__ y,
                                                   double* __restrict__ uvec) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SnDesc S = sn[level_sn[blockIdx.x]];
   const int w = S.w, r = S.r, u = r - w;
   const double* __restrict__ P = L + S.Loff;
-  double* f = lds;       // r
-  double* xs = lds + r;  // w
-  for (int t = tid; t < r; t += FB) f[t] = (t < w) ? y[S.c0 + t] : 0.0;
+  double* f = lds;              // r
+  double* xs = f + r;           // w
+  double* ps = xs + w;          // 8 x w partial sums of the triangular product
+  double* part = ps + 8 * w;    // <= 1024 partial sums of the rectangular product
+  for (int t = tid; t < r; t += SB) f[t] = (t < w) ? y[S.c0 + t] : 0.0;
   __syncthreads();
   for (int ci = S.child_begin; ci < S.child_end; ++ci) {
     const SnDesc Cd = sn[child_idx[ci]];
     const int uc = Cd.r - Cd.w;
     const double* __restrict__ uv = uvec + Cd.uoff;
     const int* __restrict__ rc = rel + Cd.reloff;
-    for (int a = tid; a < uc; a += FB) f[rc[a]] += uv[a];
+    for (int a = tid; a < uc; a += SB) f[rc[a]] += uv[a];
     __syncthreads();
   }
-  // x = inv(L11) f_top
-  for (int k = tid; k < w; k += FB) {
+  // x = inv(L11) f_top: row k, eighth p of the column range [0, k)
+  {
+    const int k = tid & 127, p = tid >> 7;
+    if (k < w) {
+      const int lo = (int)(((long long)k * p) >> 3), hi = (int)(((long long)k * (p + 1)) >> 3);
+      const double* Xk = P + k;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int t = lo;
+      for (; t + 3 < hi; t += 4) {
+        s0 += Xk[(long long)t * r] * f[t];
+        s1 += Xk[(long long)(t + 1) * r] * f[t + 1];
+        s2 += Xk[(long long)(t + 2) * r] * f[t + 2];
+        s3 += Xk[(long long)(t + 3) * r] * f[t + 3];
+      }
+      for (; t < hi; ++t) s0 += Xk[(long long)t * r] * f[t];
+      ps[p * w + k] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < w; k += SB) {
     double s = f[k];
-    const double* Xk = P + k;
-    for (int t = 0; t < k; ++t) s += Xk[(long long)t * r] * f[t];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s += ps[p * w + k];
     xs[k] = s;
     y[S.c0 + k] = s;
   }
   __syncthreads();
-  double* __restrict__ us = uvec + S.uoff;
-  for (int a = tid; a < u; a += FB) {
-    double s = f[w + a];
-    const double* Lr = P + w + a;
-    for (int k = 0; k < w; ++k) s -= Lr[(long long)k * r] * xs[k];
-    us[a] = s;
+  if (u > 0) {
+    // u_s = f_below - L21 x: 64-row chunks x column slices, fixed-order reduction
+    const int nchunk = (u + 63) >> 6;
+    const int nslice = nchunk >= 16 ? 1 : 16 / nchunk;
+    if (nslice == 1) {
+      double* __restrict__ us = uvec + S.uoff;
+      for (int ch = wave; ch < nchunk; ch += 16) {
+        const int a = (ch << 6) + lane;
+        if (a < u) {
+          const double* Lr = P + w + a;
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+          int k = 0;
+          for (; k + 3 < w; k += 4) {
+            s0 += Lr[(long long)k * r] * xs[k];
+            s1 += Lr[(long long)(k + 1) * r] * xs[k + 1];
+            s2 += Lr[(long long)(k + 2) * r] * xs[k + 2];
+            s3 += Lr[(long long)(k + 3) * r] * xs[k + 3];
+          }
+          for (; k < w; ++k) s0 += Lr[(long long)k * r] * xs[k];
+          us[a] = f[w + a] - ((s0 + s1) + (s2 + s3));
+        }
+      }
+    } else {
+      const int ch = wave % nchunk, sl = wave / nchunk;
+      if (sl < nslice) {
+        const int a = (ch << 6) + lane;
+        const int lo = (int)(((long long)w * sl) / nslice), hi = (int)(((long long)w * (sl + 1)) / nslice);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (a < u) {
+          const double* Lr = P + w + a;
+          int k = lo;
+          for (; k + 3 < hi; k += 4) {
+            s0 += Lr[(long long)k * r] * xs[k];
+            s1 += Lr[(long long)(k + 1) * r] * xs[k + 1];
+            s2 += Lr[(long long)(k + 2) * r] * xs[k + 2];
+            s3 += Lr[(long long)(k + 3) * r] * xs[k + 3];
+          }
+          for (; k < hi; ++k) s0 += Lr[(long long)k * r] * xs[k];
+        }
+        part[sl * (nchunk << 6) + (ch << 6) + lane] = (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+      double* __restrict__ us = uvec + S.uoff;
+      for (int a = tid; a < u; a += SB) {
+        double s = 0.0;
+        for (int sl2 = 0; sl2 < nslice; ++sl2) s += part[sl2 * (nchunk << 6) + a];
+        us[a] = f[w + a] - s;
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(FB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+__global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rows,
                                                   double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -376,22 +532,56 @@ __global__ __launch_bounds__(FB) void k_bwd_level(const SnDesc* __restrict__ sn,
   const int* __restrict__ rw = rows + S.rowoff + w;
   double* g = lds;      // u
   double* v = lds + u;  // w
-  for (int a = tid; a < u; a += FB) g[a] = y[rw[a]];
+  for (int a = tid; a < u; a += SB) g[a] = y[rw[a]];
   __syncthreads();
-  for (int k = wave; k < w; k += 4) {
-    const double* col = P + w + (long long)k * r;
-    double s = 0.0;
-    for (int a = lane; a < u; a += 64) s += col[a] * g[a];
-    s = wave_sum(s);
-    if (lane == 0) v[k] = y[S.c0 + k] / P[k + (long long)k * r] - s;
+  // v_k = z_k / d_k - L21(:,k)^T g : four columns per wave and pass
+  for (int k0 = 4 * wave; k0 < w; k0 += 64) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c;
+      if (k < w) {
+        const double* col = P + w + (long long)k * r;
+        for (int a = lane; a < u; a += 64) s[c] += col[a] * g[a];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        if (k < w) v[k] = y[S.c0 + k] / P[k + (long long)k * r] - s[c];
+      }
+    }
   }
   __syncthreads();
-  for (int k = wave; k < w; k += 4) {
-    const double* col = P + (long long)k * r;
-    double s = 0.0;
-    for (int t = k + 1 + lane; t < w; t += 64) s += col[t] * v[t];
-    s = wave_sum(s);
-    if (lane == 0) y[S.c0 + k] = v[k] + s;
+  // x_k = v_k + inv(L11)(:,k)^T v below the diagonal
+  for (int k0 = 4 * wave; k0 < w; k0 += 64) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c;
+      if (k < w) {
+        const double* col = P + (long long)k * r;
+        for (int t = k + 1 + lane; t < w; t += 64) s[c] += col[t] * v[t];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        if (k < w) y[S.c0 + k] = v[k] + s[c];
+      }
+    }
   }
 }
 
