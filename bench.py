@@ -177,7 +177,8 @@ def main():
         step()
     fact.synchronize()
     prof = {}
-    for cls in ("memset", "mvals", "gather", "factor", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"):
+    for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "fwd", "bwd", "rhs",
+                "xupd", "resid", "axpy", "perm"):
         ms, cnt = fact.info(f"prof_{cls}_ms"), fact.info(f"prof_{cls}_count")
         if cnt > 0:
             prof[cls] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps,
@@ -196,20 +197,29 @@ def main():
     if rank == 0:
         fbytes, sbytes, nnzL = algorithmic_bytes(fact)
         dom = max(prof, key=lambda k: prof[k]["ms_per_step"]) if prof else "factor"
-        kernel_names = {"factor": "k_factor_level", "fwd": "k_fwd_level", "bwd": "k_bwd_level", "mvals": "k_mvals_prod",
-                        "memset": "hipMemsetAsync(L arena)"}
+        kernel_names = {"factor": "k_factor_level", "factorA": "k_front_assemble", "factorB": "k_front_pivot",
+                        "factorC": "k_front_panel", "factorD": "k_front_schur", "fwd": "k_fwd_level",
+                        "bwd": "k_bwd_level", "mvals": "k_mvals_prod", "memset": "hipMemsetAsync(L arena)"}
+        launches = prof[dom]["launches_per_step"]
+        # algorithmic bytes attributable to the dominant kernel, per launch:
+        #   factor kernels: write L once + read it once for the updates (16 B/entry) + row indices (4 B) of the
+        #   fronts that kernel family processes; the split phases A-D share their fronts' bytes.
         if dom == "factor":
-            # one factorisation = nlevels launches of k_factor_level; algorithmic bytes per launch
-            launches = prof[dom]["launches_per_step"]
-            bytes_per_launch = fbytes / launches
+            step_bytes = 16 * fact.info("ent_fused") + 4 * fact.info("rows_fused")
+        elif dom in ("factorA", "factorB", "factorC", "factorD"):
+            fam = sum(prof[k]["ms_per_step"] for k in ("factorA", "factorB", "factorC", "factorD") if k in prof)
+            step_bytes = (16 * fact.info("ent_split") + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
         elif dom in ("fwd", "bwd"):
-            launches = prof[dom]["launches_per_step"]
-            bytes_per_launch = (sbytes / 2) * (1 + args.refine) * args.solves_per_factor / launches
+            step_bytes = (sbytes / 2) * (1 + args.refine) * args.solves_per_factor
+        elif dom == "mvals":
+            step_bytes = 12 * fact.info("nnzK") + 8 * fact.info("nnzM")
         else:
-            launches = prof[dom]["launches_per_step"]
-            bytes_per_launch = fbytes / max(launches, 1)
+            step_bytes = fbytes
+        bytes_per_launch = step_bytes / max(launches, 1)
         avg_s = prof[dom]["avg_launch_us"] * 1e-6
         achieved = bytes_per_launch / avg_s / 1e9
+        factor_ms = sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor", "factorA", "factorB",
+                                                          "factorC", "factorD") if k in prof)
         out = {
             "metric": "KKT factor+solve/sec (numeric refactor + 1 refined solve, inputs resident in HBM)",
             "value": world * args.steps / t_max,
@@ -235,7 +245,8 @@ def main():
             "kernels": prof,
             "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3,
                            "algorithmic_GBps": sbytes * (1 + args.refine) / t_solve / 1e9},
-            "factor_only_ms": sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor") if k in prof),
+            "factor_only_ms": factor_ms,
+            "factor_family_GBps": fbytes / (factor_ms * 1e-3) / 1e9,
             "cold_set_matrix_s": t_cold,
             "analysis_s": fact.info("analysis_s"),
             "scaled_residual": resid,

@@ -10,7 +10,7 @@ J, N, cp, ri, vx, b = make_problem(wl, 0)
 f = HipFact(device=0)
 f.set_matrix(SleqpMat(N, N, cp, ri, vx))
 d_vals = torch.from_numpy(vx).cuda()
-for mask in (1, 3, 7, 15, 2, 6, 14):
+for mask in (1, 3, 7, 15, 2, 6, 14, 2|32, 2|64, 2|128, 2|32|64|128):
     f.set_option("debug_phases", mask)
     f.set_option("profile", -1); f.set_option("profile", 1)
     for _ in range(5):

@@ -70,12 +70,18 @@ struct PinBuf {
 struct LevelInfo {
   int begin = 0, count = 0;
   size_t lds_factor = 0, lds_fwd = 0, lds_bwd = 0;
+  // split mode (few, large fronts): one kernel per phase, many workgroups per front
+  bool split = false;
+  int nparts = 1;
+  long long itA = 0, itC = 0, itD = 0;  // offsets (in ints) into d_items
+  int nA = 0, nC = 0, nD = 0;           // number of (front, part) items
+  size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0;
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
-enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
-static const char* const kProfNames[PC_COUNT] = {"memset", "mvals", "gather", "factor", "fwd", "bwd",
-                                                 "rhs",    "xupd",  "resid",  "axpy",   "perm"};
+enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FACTOR_A, PC_FACTOR_B, PC_FACTOR_C, PC_FACTOR_D, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
+static const char* const kProfNames[PC_COUNT] = {"memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC",
+                                                 "factorD", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"};
 
 struct Prof {
   bool on = false;
@@ -103,13 +109,16 @@ struct hipfact_handle {
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
   int refine_steps = 1;
-  int debug_phases = 15;  // timing-only phase mask of k_factor_level (15 = everything)
+  int debug_phases = 15;
+  int split_max_fronts = 160;
+  double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
+  DevBuf d_items;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val;
@@ -250,28 +259,93 @@ static int upload_plan(hipfact_handle* h) {
   // per-level launch metadata
   h->levels.assign(P.nlevels, LevelInfo());
   size_t max_lds = 0;
+  std::vector<int> items;
   for (int l = 0; l < P.nlevels; ++l) {
     LevelInfo& li = h->levels[l];
     li.begin = P.level_ptr[l];
     li.count = P.level_ptr[l + 1] - P.level_ptr[l];
     int mw = 0, mr = 0, mu = 0;
+    double work = 0;
     for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
       const int s = P.level_sn[q];
       const int w = P.sn_c0[s + 1] - P.sn_c0[s], r = P.sn_r[s];
       mw = std::max(mw, w);
       mr = std::max(mr, r);
       mu = std::max(mu, r - w);
+      work = std::max(work, (double)r * r * w);
     }
     const size_t wp = (size_t)((mw + 15) & ~15);
-    li.lds_factor = (wp * (wp + 1) + wp + 16 * (wp + 1)) * sizeof(double);
+    const size_t needB = wp * (wp + 1) + 16 * (wp + 1);
+    const size_t needD = (size_t)128 * mw;
+    li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
+    li.lds_pivot = (wp + needB) * sizeof(double);
+    li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double);
+    li.lds_schur = (wp + needD) * sizeof(double);
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
     li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
+    // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
+    li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5) && mu > 0;
+    {
+      // assembly items: (front, target-column class) for every front that has children
+      int with_children = 0;
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q)
+        with_children += (P.child_ptr[P.level_sn[q] + 1] > P.child_ptr[P.level_sn[q]]);
+      li.nparts = with_children > 0 ? std::max(1, std::min(32, 768 / with_children)) : 1;
+      li.itA = (long long)items.size();
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+        const int s = P.level_sn[q];
+        if (P.child_ptr[s + 1] == P.child_ptr[s]) continue;
+        for (int p = 0; p < li.nparts; ++p) {
+          items.push_back(s);
+          items.push_back(p);
+          ++li.nA;
+        }
+      }
+    }
+    if (li.split) {
+      li.itC = (long long)items.size();
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+        const int s = P.level_sn[q];
+        const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
+        for (int b = 0; b < (u + 63) / 64; ++b) {
+          items.push_back(s);
+          items.push_back(b);
+          ++li.nC;
+        }
+      }
+      li.itD = (long long)items.size();
+      // heaviest strips first is irrelevant here: every tile costs the same
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+        const int s = P.level_sn[q];
+        const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
+        const int nt = (u + 63) / 64;
+        for (int I = 0; I < nt; ++I)
+          for (int J = 0; J <= I; ++J) {
+            items.push_back(s);
+            items.push_back((I << 16) | J);
+            ++li.nD;
+          }
+      }
+    }
   }
+  h->ent_fused = h->ent_split = h->rows_fused = h->rows_split = 0;
+  for (int l = 0; l < P.nlevels; ++l)
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+      const int s = P.level_sn[q];
+      const double w = P.sn_c0[s + 1] - P.sn_c0[s], r = P.sn_r[s];
+      const double ent = w * r - w * (w - 1) / 2;
+      (h->levels[l].split ? h->ent_split : h->ent_fused) += ent;
+      (h->levels[l].split ? h->rows_split : h->rows_fused) += r;
+    }
+  if ((rc = upload(h, h->d_items, items))) return rc;
   if (max_lds > 160 * 1024) {
     h->error = "front too large for LDS-resident solve vectors";
     return HIPFACT_EINTERNAL;
   }
+  for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot), reinterpret_cast<const void*>(k_front_panel),
+                         reinterpret_cast<const void*>(k_front_schur)})
+    HCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_factor_level),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level),
@@ -323,9 +397,24 @@ static int factor_async(hipfact_handle* h) {
   }
   for (int l = 0; l < P.nlevels; ++l) {
     const LevelInfo& li = h->levels[l];
-    LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
-                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(),
-                       h->d_rel.as<int>(), h->d_child.as<int>(), h->d_info.as<int>(), h->debug_phases);
+    const int* it = h->d_items.as<int>();
+    if (li.nA > 0 && (h->debug_phases & 1))
+      LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), 0, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
+             h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
+    if (li.split && h->debug_phases == 15) {
+      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(FB), li.lds_pivot, h->d_sn.as<SnDesc>(),
+             h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>());
+      if (li.nC > 0)
+        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(FB), li.lds_panel, h->d_sn.as<SnDesc>(), it + li.itC,
+               h->d_L.as<double>(), h->d_U.as<double>());
+      if (li.nD > 0)
+        LAUNCH(PC_FACTOR_D, k_front_schur, dim3(li.nD), dim3(FB), li.lds_schur, h->d_sn.as<SnDesc>(), it + li.itD,
+               h->d_L.as<double>(), h->d_U.as<double>());
+    } else {
+      LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
+             h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(),
+             h->d_child.as<int>(), h->d_info.as<int>(), h->debug_phases);
+    }
   }
   HCHECK(h, hipGetLastError());
   h->num_factor++;
@@ -904,6 +993,12 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->refine_steps = std::max(0, (int)value);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "split_max_fronts")) {
+    h->split_max_fronts = (int)value;
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "debug_phases")) {
     h->debug_phases = (int)value;
     return HIPFACT_OK;
@@ -970,7 +1065,8 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
   INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
-  INFO("rows_total", P.sn_rows.size())
+  INFO("rows_total", P.sn_rows.size()) INFO("ent_fused", h->ent_fused) INFO("ent_split", h->ent_split)
+  INFO("rows_fused", h->rows_fused) INFO("rows_split", h->rows_split)
 #undef INFO
   return HIPFACT_EINVAL;
 }

@@ -62,13 +62,14 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 }
 
 // ---------------------------------------------------------------------------
-// Front factorisation: one workgroup (4 waves) per front, all fronts of one
-// elimination-tree level per launch.  Every dense phase runs on the fp64
-// matrix cores (v_mfma_f64_16x16x4_f64, verified lane layout: A[l&15][l>>4],
-// B[l>>4][l&15], D[(l>>4)+4q][l&15]).
+// Front factorisation.  Every dense phase runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64, verified lane layout: A[l&15][l>>4], B[l>>4][l&15],
+// D[(l>>4)+4q][l&15]).
 //
-//   A0  zero the update matrix U_s
-//   A1  extend-add the children's update matrices (relative indices)
+//   A   zero the lower triangle of the update matrix U_s and extend-add the
+//       children's update matrices (relative indices).  Work is partitioned by
+//       TARGET column class (column mod nparts), so that several workgroups can
+//       assemble one front without write conflicts and in a fixed order.
 //   B   blocked LDL^T (nb = 16) of the w x w pivot block in LDS:
 //         S1  16x16 diagonal block: LDL^T and its inverse in registers of one
 //             wave (cross-lane shuffles, no memory traffic)
@@ -76,68 +77,127 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 //         S3  trailing update A_IJ -= L_Ik D L_Jk^T                (MFMA)
 //       then the inverse of the unit lower factor by recursive doubling with
 //       MFMA products, so that the solves are pure GEMVs
-//   C   L21 = P21 inv(L11)^T D^-1, operands streamed from the panel  (MFMA)
-//   D   U_s -= L21 D L21^T, 32x32 blocks per wave, operands streamed (MFMA)
+//   C   L21 = P21 inv(L11)^T D^-1, panel rows streamed, X from LDS   (MFMA)
+//   D   U_s -= L21 D L21^T in 64 x 64 tiles, both operand strips staged in
+//       LDS (k-major), 32 x 32 block per wave                        (MFMA)
 //
-// LDS: A (wp x lda, lda = wp + 1: both the row-fragment and the transposed
-// fragment reads stay <= 2-way bank conflicted), the pivots, a 16-column panel Y.
+// Levels with many fronts run the fused kernel (one workgroup per front, all
+// phases back to back); levels with few, large fronts run one kernel per phase
+// with many workgroups per front (k_front_assemble / _pivot / _panel / _schur).
+//
+// LDS layout: dd[wp] | region.  Phase B: region = A (wp x lda, lda = wp + 1: row
+// fragments and transposed fragments are both <= 2-way bank conflicted) followed
+// by the 16-column panel Y.  Phase D: region = two w x 64 operand strips.
 // ---------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ sn,
-                                                     const int* __restrict__ level_sn, double* __restrict__ L,
-                                                     double* __restrict__ U, const int* __restrict__ rel,
-                                                     const int* __restrict__ child_idx, int* __restrict__ info,
-                                                     int phases) {
-  // phases: bit mask A(1) B(2) C(4) D(8); anything but 15 is a timing-only build
-  // of the same kernel (results are then wrong by construction).
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const SnDesc S = sn[level_sn[blockIdx.x]];
-  const int w = S.w, r = S.r, u = r - w;
-  double* __restrict__ P = L + S.Loff;
-  double* __restrict__ Us = U + S.Uoff;
-  const int wp = (w + 15) & ~15;
-  const int nbk = wp >> 4;
-  const int lda = wp + 1;
-  double* A = lds;            // wp x lda
-  double* dd = A + wp * lda;  // wp pivots
-  double* Yp = dd + wp;       // wp x 16 panel (L * D of the current block column), ld = lda
+// 1/d to ~1 ulp without the IEEE division sequence: hardware estimate plus two
+// Newton steps.  Sits on the sequential pivot chain of the diagonal blocks.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  return x;
+}
 
-  // ---- A0
-  if (phases & 1) {
-  for (long long i = tid; i < (long long)u * u; i += FB) Us[i] = 0.0;
+struct FrontCtx {
+  int w, r, u, wp, nbk, lda;
+  double* P;   // panel (global)
+  double* Us;  // update matrix (global)
+  double* dd;  // pivots (LDS)
+  double* A;   // pivot block / inverse (LDS)
+  double* Yp;  // block-column panel (LDS)
+};
+
+__device__ __forceinline__ FrontCtx make_ctx(const SnDesc& S, double* L, double* U, double* lds) {
+  FrontCtx c;
+  c.w = S.w;
+  c.r = S.r;
+  c.u = S.r - S.w;
+  c.wp = (S.w + 15) & ~15;
+  c.nbk = c.wp >> 4;
+  c.lda = c.wp + 1;
+  c.P = L + S.Loff;
+  c.Us = U + S.Uoff;
+  c.dd = lds;
+  c.A = lds + c.wp;
+  c.Yp = c.A + c.wp * c.lda;
+  return c;
+}
+
+// ---- phase A (any block size; no LDS).  Fronts without children are not
+// assembled at all: their Schur update is written in assign mode (phase D).
+__device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c, const SnDesc* __restrict__ sn,
+                                             const double* __restrict__ U, const int* __restrict__ rel,
+                                             const int* __restrict__ child_idx, int part, int nparts) {
+  if (S.child_begin == S.child_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nw = blockDim.x >> 6;
+  const int w = c.w, r = c.r, u = c.u;
+  // zero the lower triangle of the U columns of this class
+  for (int jj = wave; jj < u; jj += nw) {
+    if (nparts > 1 && ((jj + w) % nparts) != part) continue;
+    double* colp = c.Us + (long long)jj * u;
+    for (int i = jj + lane; i < u; i += 64) colp[i] = 0.0;
+  }
   __syncthreads();
-  // ---- A1
   for (int ci = S.child_begin; ci < S.child_end; ++ci) {
     const SnDesc Cd = sn[child_idx[ci]];
     const int uc = Cd.r - Cd.w;
     const double* __restrict__ Uc = U + Cd.Uoff;
     const int* __restrict__ rc = rel + Cd.reloff;
-    for (int b = wave; b < uc; b += 4) {
+    for (int b = wave; b < uc; b += nw) {
       const int tb = rc[b];
-      const double* col = Uc + (long long)b * uc;
-      if (tb < w) {
-        double* dst = P + (long long)tb * r;
-        for (int a = b + lane; a < uc; a += 64) dst[rc[a]] += col[a];
-      } else {
-        double* dst = Us + (long long)(tb - w) * u - w;
-        for (int a = b + lane; a < uc; a += 64) dst[rc[a]] += col[a];
+      if (nparts > 1 && (tb % nparts) != part) continue;
+      const double* __restrict__ col = Uc + (long long)b * uc;
+      double* dst = (tb < w) ? c.P + (long long)tb * r : c.Us + (long long)(tb - w) * u - w;
+      for (int a0 = b; a0 < uc; a0 += 256) {
+        int t[4];
+        double v[4], o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = a0 + lane + 64 * q;
+          t[q] = (a < uc) ? rc[a] : -1;
+          v[q] = (a < uc) ? col[a] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (t[q] >= 0) ? dst[t[q]] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (t[q] >= 0) dst[t[q]] = o[q] + v[q];
       }
     }
     __syncthreads();
   }
-  }
-  if (!(phases & 2)) return;
+}
 
-  // ---- B: pivot block into LDS (lower triangle, identity padding)
-  for (int k = wave; k < wp; k += 4)
+// ---- phase B: pivot block in LDS -> inv(L11) (unit lower) in A, pivots in dd
+__device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases = 15) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, wp = c.wp, nbk = c.nbk, lda = c.lda;
+  double* A = c.A;
+  double* dd = c.dd;
+  double* Yp = c.Yp;
+  const double* __restrict__ P = c.P;
+  // eight columns per batch so that the panel loads are in flight together
+  for (int kk = wave; kk < wp; kk += 32)
     for (int i = lane; i < wp; i += 64) {
-      double v = (i == k) ? 1.0 : 0.0;
-      if (i < w && k < w) v = (i >= k) ? P[i + (long long)k * r] : 0.0;
-      A[i + k * lda] = v;
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        v[q] = (i == k) ? 1.0 : 0.0;
+        if (i < w && k < w) v[q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        if (k < wp) A[i + k * lda] = v[q];
+      }
     }
   __syncthreads();
 
@@ -145,12 +205,12 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     const int k0 = kb << 4;
     // S1: wave 0 factors the diagonal block and inverts its unit lower factor.
     // lane (i = li, q = lk) owns A[i][4q..4q+3] and X[i][4q..4q+3].
-    if (wave == 0) {
+    if (wave == 0 && !(phases & 32)) {
       double a[4], x[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[c] = A[(k0 + li) + (k0 + 4 * lk + c) * lda];
-        x[c] = (li == 4 * lk + c) ? 1.0 : 0.0;
+      for (int cc = 0; cc < 4; ++cc) {
+        a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
+        x[cc] = (li == 4 * lk + cc) ? 1.0 : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -165,24 +225,25 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
           dd[k0 + k] = d;
           if (d < 0.0) atomicAdd(&info[INFO_NEG_PIVOT], 1);
         }
-        const double l_ik = (li > k) ? ck_i / d : 0.0;
+        const double l_ik = (li > k) ? ck_i * fast_rcp(d) : 0.0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double xk = __shfl(x[c], (lk << 4) | k, 64);  // X[k][4q+c]
-          x[c] -= l_ik * xk;
+        for (int cc = 0; cc < 4; ++cc) {
+          const double xk = __shfl(x[cc], (lk << 4) | k, 64);  // X[k][4q+c]
+          x[cc] -= l_ik * xk;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int j = 4 * lk + c;
+        for (int cc = 0; cc < 4; ++cc) {
+          const int j = 4 * lk + cc;
           const double ck_j = __shfl(a[kr], (qk << 4) | j, 64);  // A[j][k]
-          if (j > k) a[c] -= l_ik * ck_j;
+          if (j > k) a[cc] -= l_ik * ck_j;
         }
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) A[(k0 + li) + (k0 + 4 * lk + c) * lda] = x[c];
+      for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
     }
     __syncthreads();
     // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
+    if (!(phases & 64))
     for (int I = kb + 1 + wave; I < nbk; I += 4) {
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -201,7 +262,7 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     }
     __syncthreads();
     // S3: trailing update of the lower block triangle.
-    {
+    if (!(phases & 64)) {
       const int T = nbk - kb - 1;
       const int ntiles = T * (T + 1) / 2;
       for (int t = wave; t < ntiles; t += 4) {
@@ -228,12 +289,12 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     __syncthreads();
   }
 
-  // ---- B2: inverse of the unit lower block factor by recursive doubling.
-  // A holds inv(L_kk) in the diagonal blocks and L_IJ below.  For the block
-  // [X11 0; B X22] the off-diagonal block of the inverse is -X22 B X11; one wave
-  // computes one 16-column strip of it in registers (the accumulator tiles of the
-  // first product are the B operands of the second), then all strips are stored.
-  for (int h = 16; h < wp; h <<= 1) {
+  // inverse of the unit lower block factor by recursive doubling.  A holds
+  // inv(L_kk) in the diagonal blocks and L_IJ below.  For [X11 0; B X22] the
+  // off-diagonal block of the inverse is -X22 B X11; one wave computes one
+  // 16-column strip of it in registers (the accumulator tiles of the first
+  // product are the B operands of the second), then all strips are stored.
+  for (int h = 16; h < wp && !(phases & 128); h <<= 1) {
     const int ht = h >> 4;
     const int ntask = (wp + 2 * h - 1) / (2 * h);
     const int units = ntask * ht;
@@ -286,15 +347,51 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     }
     __syncthreads();
   }
-  // store inv(L11) (strict lower) and the pivots (diagonal) back to the panel
-  for (int k = wave; k < w; k += 4)
-    for (int i = k + lane; i < w; i += 64) P[i + (long long)k * r] = (i == k) ? dd[k] : A[i + k * lda];
+}
 
-  if (!(phases & 4)) return;
-  // ---- C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel rows
-  // at a time: the B operand streams from the panel (16 consecutive rows per
-  // k-step), the A operand is X from LDS; results are stored row-contiguous.
-  for (int R0 = w + 16 * wave; R0 < r; R0 += 64) {
+// store inv(L11) (strict lower) and the pivots (diagonal) back to the panel
+__device__ __forceinline__ void dev_store_pivot_block(const FrontCtx& c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < c.w; k += 4)
+    for (int i = k + lane; i < c.w; i += 64)
+      c.P[i + (long long)k * c.r] = (i == k) ? c.dd[k] : c.A[i + k * c.lda];
+}
+
+// reload inv(L11) and the pivots from a finished panel (split kernels)
+__device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool need_x) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < c.wp; k += FB) c.dd[k] = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
+  if (need_x)
+    for (int kk = wave; kk < c.wp; kk += 32)
+      for (int i = lane; i < c.wp; i += 64) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = kk + 4 * q;
+          v[q] = (i == k) ? 1.0 : 0.0;
+          if (i < c.w && k < c.w && i > k) v[q] = c.P[i + (long long)k * c.r];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = kk + 4 * q;
+          if (k < c.wp) c.A[i + k * c.lda] = v[q];
+        }
+      }
+  __syncthreads();
+}
+
+// ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
+// rows at a time: the B operand streams from the panel (16 consecutive rows per
+// k-step), the A operand is X from LDS; results are stored row-contiguous.
+// Row blocks blk, blk + nblk_stride, ... (64 rows each).
+__device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
+  const double* A = c.A;
+  const double* dd = c.dd;
+  double* __restrict__ P = c.P;
+  for (int R0 = w + 64 * blk + 16 * wave; R0 < r; R0 += 64 * blk_stride) {
     const bool rok = (R0 + li) < r;
     const double* __restrict__ Prow = P + R0 + li;
     d4_t acc[8];
@@ -338,77 +435,150 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
         }
     }
   }
-  __syncthreads();
+}
 
-  // ---- D: U_s -= L21 D L21^T.  One 32 x 32 block of the lower triangle per
-  // wave and iteration; computed transposed (rows of the accumulator = j) so that
-  // the read-modify-write of U is contiguous in i.
-  if (u > 0 && (phases & 8)) {
-    const double* __restrict__ P21 = P + w;
-    const int nb32 = (u + 31) >> 5;
-    const long long nblk = (long long)nb32 * (nb32 + 1) / 2;
-    int J = 0;
-    long long base = 0;  // first block index of block column J
-    for (long long blk = wave; blk < nblk; blk += 4) {
-      while (blk - base >= nb32 - J) {
-        base += nb32 - J;
-        ++J;
-      }
-      const int I = J + (int)(blk - base);
-      const int i0 = 32 * I, j0 = 32 * J;
-      d4_t acc[2][2];
+// ---- phase D: one 64 x 64 tile (I, J) of U_s -= L21 D L21^T.  Operand strips
+// (64 rows x w, k-major) staged in LDS; strip I is reused while `stage_i` is false.
+__device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool stage_i,
+                                               bool assign) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, u = c.u;
+  const double* __restrict__ P21 = c.P + w;
+  __syncthreads();  // previous tile has finished reading the strips
+  {
+    const int i = tid & 63;
+    const bool iok = (64 * I + i) < u, jok = (64 * J + i) < u;
+    const double* __restrict__ pi = P21 + 64 * I + i;
+    const double* __restrict__ pj = P21 + 64 * J + i;
+    for (int kk = tid >> 6; kk < w; kk += 32) {
+      double vi[8], vj[8];
 #pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
-      const bool jok0 = (j0 + li) < u, jok1 = (j0 + 16 + li) < u;
-      const bool iok0 = (i0 + li) < u, iok1 = (i0 + 16 + li) < u;
-      const double* __restrict__ Pj = P21 + j0 + li;
-      const double* __restrict__ Pi = P21 + i0 + li;
-      double aj0, aj1, bi0, bi1;
-      {
-        const bool kok = lk < w;
-        const long long off = (long long)lk * r;
-        const double dk = kok ? dd[lk] : 0.0;
-        aj0 = (kok && jok0) ? Pj[off] * dk : 0.0;
-        aj1 = (kok && jok1) ? Pj[off + 16] * dk : 0.0;
-        bi0 = (kok && iok0) ? Pi[off] : 0.0;
-        bi1 = (kok && iok1) ? Pi[off + 16] : 0.0;
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        vi[q] = (stage_i && iok && k < w) ? pi[(long long)k * r] : 0.0;
+        vj[q] = (jok && k < w) ? pj[(long long)k * r] : 0.0;
       }
-      for (int k0 = 0; k0 < w; k0 += 4) {
-        double naj0 = 0.0, naj1 = 0.0, nbi0 = 0.0, nbi1 = 0.0;
-        const int kn = k0 + 4 + lk;
-        if (kn < w) {
-          const long long off = (long long)kn * r;
-          const double dk = dd[kn];
-          if (jok0) naj0 = Pj[off] * dk;
-          if (jok1) naj1 = Pj[off + 16] * dk;
-          if (iok0) nbi0 = Pi[off];
-          if (iok1) nbi1 = Pi[off + 16];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        if (k < w) {
+          if (stage_i) SI[k * 64 + i] = vi[q];
+          SJ[k * 64 + i] = vj[q] * c.dd[k];
         }
-        acc[0][0] = MFMA_F64(aj0, bi0, acc[0][0]);
-        acc[0][1] = MFMA_F64(aj0, bi1, acc[0][1]);
-        acc[1][0] = MFMA_F64(aj1, bi0, acc[1][0]);
-        acc[1][1] = MFMA_F64(aj1, bi1, acc[1][1]);
-        aj0 = naj0;
-        aj1 = naj1;
-        bi0 = nbi0;
-        bi1 = nbi1;
       }
-      // acc[x][y][q] = update of U(i = i0 + 16 y + li, j = j0 + 16 x + lk + 4 q)
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int i = i0 + 16 * y + li;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = j0 + 16 * x + lk + 4 * q;
-            if (i < u && j < u && i >= j) Us[i + (long long)j * u] -= acc[x][y][q];
-          }
-        }
     }
   }
+  __syncthreads();
+  const int wi = wave & 1, wj = wave >> 1;
+  if (I == J && wi < wj) return;  // block above the diagonal
+  const int i0 = 32 * wi, j0 = 32 * wj;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  const int w4 = w & ~3;
+  for (int k0 = 0; k0 < w4; k0 += 4) {
+    const int kk = (k0 + lk) * 64;
+    const double a0 = SJ[kk + j0 + li], a1 = SJ[kk + j0 + 16 + li];
+    const double b0 = SI[kk + i0 + li], b1 = SI[kk + i0 + 16 + li];
+    acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+    acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
+    acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
+    acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+  }
+  if (w4 < w) {
+    const bool kok = (w4 + lk) < w;
+    const int kk = (w4 + lk) * 64;
+    const double a0 = kok ? SJ[kk + j0 + li] : 0.0, a1 = kok ? SJ[kk + j0 + 16 + li] : 0.0;
+    const double b0 = kok ? SI[kk + i0 + li] : 0.0, b1 = kok ? SI[kk + i0 + 16 + li] : 0.0;
+    acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+    acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
+    acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
+    acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+  }
+  // acc[x][y][q] = update of U(i = 64 I + i0 + 16 y + li, j = 64 J + j0 + 16 x + lk + 4 q)
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int i = 64 * I + i0 + 16 * y + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
+        if (i < u && j < u && i >= j) {
+          double* dst = c.Us + i + (long long)j * u;
+          *dst = assign ? -acc[x][y][q] : *dst - acc[x][y][q];
+        }
+      }
+    }
+}
+
+// fused: one workgroup per front, phases B, C, D (assembly has its own kernel)
+__global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ sn,
+                                                     const int* __restrict__ level_sn, double* __restrict__ L,
+                                                     double* __restrict__ U, const int* __restrict__ rel,
+                                                     const int* __restrict__ child_idx, int* __restrict__ info,
+                                                     int phases) {
+  // phases: bit mask A(1) B(2) C(4) D(8); anything but 15 is a timing-only build
+  // of the same kernel (results are then wrong by construction).
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SnDesc S = sn[level_sn[blockIdx.x]];
+  const FrontCtx c = make_ctx(S, L, U, lds);
+  if (!(phases & 2)) return;
+  dev_pivot_block(c, info, phases);
+  dev_store_pivot_block(c);
+  if (!(phases & 4)) return;
+  dev_panel_solve(c, 0, 1);
+  __syncthreads();
+  if (c.u > 0 && (phases & 8)) {
+    double* SI = c.A;
+    double* SJ = c.A + 64 * c.w;
+    const int nt = (c.u + 63) >> 6;
+    for (int I = 0; I < nt; ++I)
+      for (int J = 0; J <= I; ++J) dev_schur_tile(c, SI, SJ, I, J, J == 0, S.child_begin == S.child_end);
+  }
+}
+
+// split kernels: items[2 * blockIdx.x] = supernode, items[2 * blockIdx.x + 1] = part
+__global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restrict__ sn, const int* __restrict__ items,
+                                                       int nparts, double* __restrict__ L, double* __restrict__ U,
+                                                       const int* __restrict__ rel,
+                                                       const int* __restrict__ child_idx) {
+  const SnDesc S = sn[items[2 * blockIdx.x]];
+  FrontCtx c = make_ctx(S, L, U, nullptr);
+  dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts);
+}
+
+__global__ __launch_bounds__(FB) void k_front_pivot(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+                                                    double* __restrict__ L, double* __restrict__ U,
+                                                    int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SnDesc S = sn[level_sn[blockIdx.x]];
+  const FrontCtx c = make_ctx(S, L, U, lds);
+  dev_pivot_block(c, info);
+  dev_store_pivot_block(c);
+}
+
+__global__ __launch_bounds__(FB) void k_front_panel(const SnDesc* __restrict__ sn, const int* __restrict__ items,
+                                                    double* __restrict__ L, double* __restrict__ U) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SnDesc S = sn[items[2 * blockIdx.x]];
+  const FrontCtx c = make_ctx(S, L, U, lds);
+  dev_load_pivot_block(c, true);
+  dev_panel_solve(c, items[2 * blockIdx.x + 1], 1 << 24);
+}
+
+// items: supernode, (I << 16) | J
+__global__ __launch_bounds__(FB) void k_front_schur(const SnDesc* __restrict__ sn, const int* __restrict__ items,
+                                                    double* __restrict__ L, double* __restrict__ U) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SnDesc S = sn[items[2 * blockIdx.x]];
+  const FrontCtx c = make_ctx(S, L, U, lds);
+  dev_load_pivot_block(c, false);
+  const int ij = items[2 * blockIdx.x + 1];
+  dev_schur_tile(c, c.A, c.A + 64 * c.w, ij >> 16, ij & 0xffff, true, S.child_begin == S.child_end);
 }
 
 // ---------------------------------------------------------------------------
