@@ -702,17 +702,44 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
   const int* __restrict__ rw = rows + S.rowoff + w;
   double* g = lds;      // u
   double* v = lds + u;  // w
-  for (int a = tid; a < u; a += SB) g[a] = y[rw[a]];
-  __syncthreads();
-  // v_k = z_k / d_k - L21(:,k)^T g : four columns per wave and pass
-  for (int k0 = 4 * wave; k0 < w; k0 += 64) {
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
+  // columns of this wave: k = 4 (wave + 16 p) + c, p = 0, 1 (w <= 128)
+  const bool pre = (u <= 256);
+  double lv[2][4][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int k = k0 + c;
-      if (k < w) {
-        const double* col = P + w + (long long)k * r;
-        for (int a = lane; a < u; a += 64) s[c] += col[a] * g[a];
+      const int k = 4 * (wave + 16 * p) + c;
+      const double* col = P + (long long)k * r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = lane + 64 * q;
+        lv[p][c][q] = (pre && k < w && a < u) ? col[w + a] : 0.0;
+      }
+    }
+  for (int a = tid; a < u; a += SB) g[a] = y[rw[a]];
+  __syncthreads();
+  // v_k = z_k / d_k - L21(:,k)^T g
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (4 * (wave + 16 * p) >= w) continue;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (pre) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = lane + 64 * q;
+          if (a < u) s[c] += lv[p][c][q] * g[a];
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * (wave + 16 * p) + c;
+        if (k < w) {
+          const double* col = P + w + (long long)k * r;
+          for (int a = lane; a < u; a += 64) s[c] += col[a] * g[a];
+        }
       }
     }
 #pragma unroll
@@ -723,21 +750,38 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
     if (lane == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int k = k0 + c;
+        const int k = 4 * (wave + 16 * p) + c;
         if (k < w) v[k] = y[S.c0 + k] / P[k + (long long)k * r] - s[c];
       }
     }
   }
+  // fragments of inv(L11) for the second product (in flight across the barrier)
+  double xv[2][4][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * (wave + 16 * p) + c;
+      const double* col = P + (long long)k * r;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = k + 1 + lane + 64 * q;
+        xv[p][c][q] = (k < w && t < w) ? col[t] : 0.0;
+      }
+    }
   __syncthreads();
   // x_k = v_k + inv(L11)(:,k)^T v below the diagonal
-  for (int k0 = 4 * wave; k0 < w; k0 += 64) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (4 * (wave + 16 * p) >= w) continue;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int k = k0 + c;
-      if (k < w) {
-        const double* col = P + (long long)k * r;
-        for (int t = k + 1 + lane; t < w; t += 64) s[c] += col[t] * v[t];
+      const int k = 4 * (wave + 16 * p) + c;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = k + 1 + lane + 64 * q;
+        if (k < w && t < w) s[c] += xv[p][c][q] * v[t];
       }
     }
 #pragma unroll
@@ -748,7 +792,7 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
     if (lane == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int k = k0 + c;
+        const int k = 4 * (wave + 16 * p) + c;
         if (k < w) y[S.c0 + k] = v[k] + s[c];
       }
     }
