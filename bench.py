@@ -104,17 +104,10 @@ def main():
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from sleqp_amd.replicas import Replicas
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    rep = Replicas()
+    rank, local_rank, world, dist = rep.rank, rep.local_rank, rep.world, rep.dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hipfact backend has no CPU path)")
     dev = torch.device("cuda", local_rank)
@@ -123,7 +116,7 @@ def main():
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
-    J, N, cp, ri, vx, b = make_problem(args.workload, seed=rank)
+    J, N, cp, ri, vx, b = make_problem(args.workload, seed=rep.problem_seed())
     fact = HipFact(device=local_rank, refine_steps=args.refine)
     t0 = time.perf_counter()
     fact.set_matrix(SleqpMat(N, N, cp, ri, vx))  # cold call: analysis + upload + first factorisation
@@ -140,8 +133,7 @@ def main():
             fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        rep.barrier()
         torch.cuda.synchronize()
         fact.synchronize()
 
@@ -154,13 +146,8 @@ def main():
     fact.synchronize()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([t_local], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-    else:
-        t_max = t_local
+    rep.barrier()
+    t_max = rep.max_over_ranks(t_local)
 
     # correctness of what was timed (scaled residual of the last solve)
     from sleqp_amd import synth
@@ -222,7 +209,7 @@ def main():
                                                           "factorC", "factorD") if k in prof)
         out = {
             "metric": "KKT factor+solve/sec (numeric refactor + 1 refined solve, inputs resident in HBM)",
-            "value": world * args.steps / t_max,
+            "value": rep.aggregate_rate(args.steps, t_max),
             "unit": "factor+solve/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -254,9 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, cp, ri, vx, b)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rep.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,248 @@
+/* aug_jac_hipfact.c — the optional second boundary: a SleqpAugJac
+ * (aug_jac/aug_jac_types.h:27-35, created like aug_jac/standard_aug_jac.c:525-547)
+ * that never builds K on the host.  set_iterate hands the constraint Jacobian
+ * and the working-set index maps to hipfact_assemble_kkt, which restates
+ * fill_aug_jac (standard_aug_jac.c:135-237) on the device, factors K there and
+ * keeps it resident; the three solves are the same rhs padding / shifting as
+ * standard_aug_jac.c:306-435, driven through the C ABI.
+ *
+ * Hook: in create_aug_jac (trial_point.c:105-108) replace
+ *   sleqp_standard_aug_jac_create(star, problem, settings, fact)
+ * by sleqp_hipfact_aug_jac_create(star, problem, settings) when
+ * SLEQP_FACT_HIPFACT is the configured backend.
+ */
+#include "aug_jac_hipfact.h"
+
+#include <assert.h>
+
+#ifndef HIPFACT_STANDALONE
+#include "error.h"
+#include "fail.h"
+#include "iterate.h"
+#include "mem.h"
+#include "problem.h"
+#include "working_set.h"
+#endif
+
+#include "hipfact.h"
+
+typedef struct
+{
+  SleqpProblem* problem;
+  hipfact_handle* handle;
+
+  int working_set_size;
+  double condition;
+  double zero_eps;
+
+  int* var_index;  /* num_variables */
+  int* cons_index; /* num_constraints */
+  double* slice;   /* dense staging for hipfact_solution */
+} AugJacData;
+
+#define HIPFACT_CALL(data, x)                                                  \
+  do                                                                           \
+  {                                                                            \
+    const int hipfact_status = (x);                                            \
+    if (hipfact_status != HIPFACT_OK)                                          \
+    {                                                                          \
+      sleqp_raise(SLEQP_INTERNAL_ERROR,                                        \
+                  "Caught hipfact error <%d> (%s)",                            \
+                  hipfact_status,                                              \
+                  hipfact_last_error((data)->handle));                         \
+    }                                                                          \
+  } while (0)
+
+static SLEQP_RETCODE
+aug_jac_set_iterate(SleqpIterate* iterate, void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  SleqpProblem* problem        = jacobian->problem;
+  SleqpMat* cons_jac           = sleqp_iterate_cons_jac(iterate);
+  SleqpWorkingSet* working_set = sleqp_iterate_working_set(iterate);
+
+  const int num_variables   = sleqp_problem_num_vars(problem);
+  const int num_constraints = sleqp_problem_num_cons(problem);
+
+  for (int j = 0; j < num_variables; ++j)
+  {
+    jacobian->var_index[j] = sleqp_working_set_var_index(working_set, j);
+  }
+
+  for (int i = 0; i < num_constraints; ++i)
+  {
+    jacobian->cons_index[i] = sleqp_working_set_cons_index(working_set, i);
+  }
+
+  jacobian->working_set_size = sleqp_working_set_size(working_set);
+  jacobian->condition        = SLEQP_NONE;
+
+  /* assembly + factorisation on the device; K never exists on the host */
+  HIPFACT_CALL(jacobian,
+               hipfact_assemble_kkt(jacobian->handle,
+                                    num_variables,
+                                    num_constraints,
+                                    sleqp_mat_cols(cons_jac),
+                                    sleqp_mat_rows(cons_jac),
+                                    sleqp_mat_data(cons_jac),
+                                    jacobian->var_index,
+                                    jacobian->cons_index,
+                                    jacobian->working_set_size,
+                                    NULL,
+                                    NULL,
+                                    NULL,
+                                    NULL));
+
+  HIPFACT_CALL(jacobian, hipfact_condition(jacobian->handle, &jacobian->condition));
+
+  return SLEQP_OKAY;
+}
+
+static SLEQP_RETCODE
+aug_jac_condition(bool* exact, double* condition, void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  *exact     = false;
+  *condition = jacobian->condition;
+
+  return SLEQP_OKAY;
+}
+
+static SLEQP_RETCODE
+solve_and_extract(AugJacData* jacobian, const SleqpVec* rhs, int total_size, SleqpVec* sol, int begin, int end)
+{
+  HIPFACT_CALL(jacobian, hipfact_solve_sparse(jacobian->handle, total_size, rhs->nnz, rhs->indices, rhs->data));
+
+  HIPFACT_CALL(jacobian, hipfact_solution(jacobian->handle, jacobian->slice, begin, end));
+
+  SLEQP_CALL(sleqp_vec_set_from_raw(sol, jacobian->slice, end - begin, jacobian->zero_eps));
+
+  return SLEQP_OKAY;
+}
+
+static SLEQP_RETCODE
+aug_jac_solve_min_norm(const SleqpVec* _rhs, SleqpVec* sol, void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  /* Cast away constness: the indices are shifted in place around the call,
+   * exactly like standard_aug_jac.c:328-345 */
+  SleqpVec* rhs = (SleqpVec*)_rhs;
+
+  const int num_variables = sleqp_problem_num_vars(jacobian->problem);
+  const int total_size    = num_variables + jacobian->working_set_size;
+
+  assert(rhs->dim == jacobian->working_set_size);
+
+  for (int k = 0; k < rhs->nnz; ++k)
+  {
+    rhs->indices[k] += num_variables;
+  }
+
+  SLEQP_RETCODE status = solve_and_extract(jacobian, rhs, total_size, sol, 0, num_variables);
+
+  for (int k = 0; k < rhs->nnz; ++k)
+  {
+    rhs->indices[k] -= num_variables;
+  }
+
+  return status;
+}
+
+static SLEQP_RETCODE
+aug_jac_solve_lsq(const SleqpVec* rhs, SleqpVec* sol, void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  const int num_variables = sleqp_problem_num_vars(jacobian->problem);
+  const int total_size    = num_variables + jacobian->working_set_size;
+
+  assert(rhs->dim == num_variables);
+
+  /* "just add some zeros" (standard_aug_jac.c:375-376): the padded vector has
+   * the same nonzeros, only a larger dimension */
+  SLEQP_CALL(solve_and_extract(jacobian, rhs, total_size, sol, num_variables, total_size));
+
+  return SLEQP_OKAY;
+}
+
+static SLEQP_RETCODE
+aug_jac_project_nullspace(const SleqpVec* rhs, SleqpVec* sol, void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  const int num_variables = sleqp_problem_num_vars(jacobian->problem);
+  const int total_size    = num_variables + jacobian->working_set_size;
+
+  assert(rhs->dim == num_variables);
+
+  SLEQP_CALL(solve_and_extract(jacobian, rhs, total_size, sol, 0, num_variables));
+
+  return SLEQP_OKAY;
+}
+
+static SLEQP_RETCODE
+aug_jac_free(void* data)
+{
+  AugJacData* jacobian = (AugJacData*)data;
+
+  hipfact_free(&jacobian->handle);
+
+  sleqp_free(&jacobian->slice);
+  sleqp_free(&jacobian->cons_index);
+  sleqp_free(&jacobian->var_index);
+
+  SLEQP_CALL(sleqp_problem_release(&jacobian->problem));
+
+  sleqp_free(&jacobian);
+
+  return SLEQP_OKAY;
+}
+
+SLEQP_RETCODE
+sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSettings* settings)
+{
+  AugJacData* jacobian = NULL;
+
+  SLEQP_CALL(sleqp_malloc(&jacobian));
+
+  *jacobian = (AugJacData){0};
+
+  const int num_variables   = sleqp_problem_num_vars(problem);
+  const int num_constraints = sleqp_problem_num_cons(problem);
+
+  SLEQP_CALL(sleqp_problem_capture(problem));
+  jacobian->problem   = problem;
+  jacobian->condition = SLEQP_NONE;
+
+#ifdef HIPFACT_STANDALONE
+  jacobian->zero_eps = sleqp_settings_zero_eps(settings);
+#else
+  jacobian->zero_eps = sleqp_settings_real_value(settings, SLEQP_SETTINGS_REAL_ZERO_EPS);
+#endif
+
+  SLEQP_CALL(sleqp_alloc_array(&jacobian->var_index, num_variables));
+  SLEQP_CALL(sleqp_alloc_array(&jacobian->cons_index, num_constraints));
+  /* |W| <= n (pub_working_set.h:12-13): n doubles cover both solution slices */
+  SLEQP_CALL(sleqp_alloc_array(&jacobian->slice, 2 * num_variables + num_constraints));
+
+  const int status = hipfact_create(&jacobian->handle, -1);
+
+  if (status != HIPFACT_OK)
+  {
+    sleqp_raise(SLEQP_INTERNAL_ERROR, "Failed to create hipfact backend <%d> (%s)", status, hipfact_last_error(NULL));
+  }
+
+  SleqpAugJacCallbacks callbacks = {.set_iterate       = aug_jac_set_iterate,
+                                    .solve_min_norm    = aug_jac_solve_min_norm,
+                                    .solve_lsq         = aug_jac_solve_lsq,
+                                    .project_nullspace = aug_jac_project_nullspace,
+                                    .condition         = aug_jac_condition,
+                                    .free              = aug_jac_free};
+
+  SLEQP_CALL(sleqp_aug_jac_create(star, problem, &callbacks, jacobian));
+
+  return SLEQP_OKAY;
+}
