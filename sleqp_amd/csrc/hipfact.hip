@@ -75,7 +75,7 @@ struct LevelInfo {
   int nparts = 1;
   long long itA = 0, itC = 0, itD = 0;  // offsets (in ints) into d_items
   int nA = 0, nC = 0, nD = 0;           // number of (front, part) items
-  size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0;
+  size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0, lds_asm = 0;
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
@@ -109,6 +109,19 @@ struct hipfact_handle {
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
   int refine_steps = 1;
+  bool refine_adaptive = true;   // run the correction pass only when the residual asks for it
+  double refine_tol = 5e-13;     // on ||b - K z||_inf / ||b||_inf
+  long num_refined = 0;          // solves that needed a correction pass
+  bool use_graph = true;         // replay captured hipGraphs instead of re-enqueueing ~100 launches
+  struct GraphEntry {
+    int kind;  // 0 factor, 1 solve first pass (+ residual, norms), 2 correction pass
+    const void* b;
+    void* z;
+    int refine_steps;
+    bool adaptive;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 160;
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
@@ -121,7 +134,8 @@ struct hipfact_handle {
   DevBuf d_items;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
-  DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val;
+  DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
+  PinBuf h_norms;
   PinBuf h_stage, h_info;
   // assembly
   DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
@@ -281,6 +295,7 @@ static int upload_plan(hipfact_handle* h) {
     li.lds_pivot = (wp + needB) * sizeof(double);
     li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double);
     li.lds_schur = (wp + needD) * sizeof(double);
+    li.lds_asm = ((size_t)P.max_u + 16) * sizeof(int);
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
     li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
@@ -365,12 +380,14 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_corr.ensure(nb));
   HCHECK(h, h->d_info.ensure(INFO_WORDS * sizeof(int)));
   HCHECK(h, h->d_minmax.ensure(2 * 64 * sizeof(double)));
+  HCHECK(h, h->d_norms.ensure(2 * sizeof(double)));
+  HCHECK(h, h->h_norms.ensure(2 * sizeof(double)));
   HCHECK(h, h->h_info.ensure(INFO_WORDS * sizeof(int) + 2 * 64 * sizeof(double)));
   return HIPFACT_OK;
 }
 
 // queue the numeric factorisation on the stream (values already in d_Kval)
-static int factor_async(hipfact_handle* h) {
+static int factor_enqueue(hipfact_handle* h) {
   const Plan& P = h->plan;
   hipStream_t st = h->stream;
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_WORDS * sizeof(int), st));
@@ -399,7 +416,7 @@ static int factor_async(hipfact_handle* h) {
     const LevelInfo& li = h->levels[l];
     const int* it = h->d_items.as<int>();
     if (li.nA > 0 && (h->debug_phases & 1))
-      LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), 0, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
+      LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), li.lds_asm, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
              h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
     if (li.split && h->debug_phases == 15) {
       LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(FB), li.lds_pivot, h->d_sn.as<SnDesc>(),
@@ -417,6 +434,15 @@ static int factor_async(hipfact_handle* h) {
     }
   }
   HCHECK(h, hipGetLastError());
+  return HIPFACT_OK;
+}
+
+template <class F>
+static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue);
+
+static int factor_async(hipfact_handle* h) {
+  const int rc = run_cached(h, 0, nullptr, nullptr, [&] { return factor_enqueue(h); });
+  if (rc) return rc;
   h->num_factor++;
   h->factored = true;
   h->solved = false;
@@ -488,24 +514,104 @@ static void residual_async(hipfact_handle* h, const double* b, const double* z, 
   }
 }
 
-// full solve with iterative refinement: rhs in d_rhs, result in d_sol
-static int solve_async(hipfact_handle* h, const double* b, double* z) {
+static void drop_graphs(hipfact_handle* h) {
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  h->graphs.clear();
+}
+
+// Runs `enqueue` (a function that only queues work on h->stream) through a
+// cached hipGraph; falls back to direct enqueueing when graphs are disabled,
+// while profiling with events, or when capture is not possible.
+template <class F>
+static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue) {
+  if (!h->use_graph || h->prof.on || h->debug_phases != 15) return enqueue();
+  for (auto& g : h->graphs)
+    if (g.kind == kind && g.b == b && g.z == z && g.refine_steps == h->refine_steps &&
+        g.adaptive == h->refine_adaptive) {
+      HCHECK(h, hipGraphLaunch(g.exec, h->stream));
+      return HIPFACT_OK;
+    }
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return enqueue();
+  }
+  const int rc = enqueue();
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc != HIPFACT_OK || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (rc != HIPFACT_OK) return rc;
+    h->use_graph = false;  // capture unsupported here: stay on the direct path
+    return enqueue();
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    h->use_graph = false;
+    return enqueue();
+  }
+  if (h->graphs.size() >= 16) drop_graphs(h);
+  h->graphs.push_back({kind, b, z, h->refine_steps, h->refine_adaptive, exec});
+  HCHECK(h, hipGraphLaunch(exec, h->stream));
+  return HIPFACT_OK;
+}
+
+// first pass: z = K^-1 b, then (when refinement is enabled) res = b - K z and its norms
+static int solve_first_enqueue(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
-  if (P.N == 0) return HIPFACT_OK;
-  // b may alias z: keep a private copy of b when refining
   const double* bb = b;
-  if (h->refine_steps > 0 && b == z) {
+  if (h->refine_steps > 0 && b == z) {  // keep a private copy of b for the residual
     HCHECK(h, hipMemcpyAsync(h->d_rhs.p, b, (size_t)P.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     bb = h->d_rhs.as<double>();
   }
   solve_once_async(h, bb, z);
-  for (int it = 0; it < h->refine_steps; ++it) {
+  if (h->refine_steps > 0) {
     residual_async(h, bb, z, h->d_res.as<double>());
-    solve_once_async(h, h->d_res.as<double>(), h->d_corr.as<double>());
-    LAUNCH(PC_AXPY, k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, (long long)P.N, 1.0,
-                       h->d_corr.as<double>(), z);
+    if (h->refine_adaptive) {
+      LAUNCH(PC_AXPY, k_norms, dim3(1), dim3(1024), 0, P.N, h->d_res.as<double>(), bb, h->d_norms.as<double>());
+      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
   }
   HCHECK(h, hipGetLastError());
+  return HIPFACT_OK;
+}
+
+// correction passes: z += K^-1 res, res recomputed between passes
+static int solve_correct_enqueue(hipfact_handle* h, const double* b, double* z, int passes) {
+  const Plan& P = h->plan;
+  const double* bb = (b == z) ? h->d_rhs.as<double>() : b;
+  for (int it = 0; it < passes; ++it) {
+    if (it > 0) residual_async(h, bb, z, h->d_res.as<double>());
+    solve_once_async(h, h->d_res.as<double>(), h->d_corr.as<double>());
+    LAUNCH(PC_AXPY, k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, (long long)P.N, 1.0, h->d_corr.as<double>(), z);
+  }
+  HCHECK(h, hipGetLastError());
+  return HIPFACT_OK;
+}
+
+// full solve with iterative refinement on K itself: fixed number of correction
+// passes, or (default) one pass only when the relative residual exceeds refine_tol
+static int solve_async(hipfact_handle* h, const double* b, double* z) {
+  const Plan& P = h->plan;
+  if (P.N == 0) return HIPFACT_OK;
+  int rc = run_cached(h, 1, b, z, [&] { return solve_first_enqueue(h, b, z); });
+  if (rc) return rc;
+  if (h->refine_steps > 0) {
+    bool correct = true;
+    if (h->refine_adaptive) {
+      HCHECK(h, hipStreamSynchronize(h->stream));
+      const double rn = h->h_norms.as<double>()[0], bn = h->h_norms.as<double>()[1];
+      correct = !(rn <= h->refine_tol * bn);  // also true for NaN
+    }
+    if (correct) {
+      h->num_refined++;
+      rc = run_cached(h, 2, b, z, [&] { return solve_correct_enqueue(h, b, z, h->refine_steps); });
+      if (rc) return rc;
+    }
+  }
   h->num_solve++;
   h->solved = true;
   return HIPFACT_OK;
@@ -528,6 +634,7 @@ static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* r
   }
   h->have_plan = false;
   h->factored = false;
+  drop_graphs(h);
   try {
     if (!build_plan(N, colptr, rowidx, vals, h->prm, h->plan)) {
       h->error = h->plan.error;
@@ -606,6 +713,7 @@ int hipfact_free(hipfact_handle** handle) {
   (void)hipSetDevice(h->device);
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
     (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -993,8 +1101,22 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->refine_steps = std::max(0, (int)value);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "refine_adaptive")) {
+    h->refine_adaptive = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "refine_tol")) {
+    h->refine_tol = value;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "use_graph")) {
+    h->use_graph = value != 0.0;
+    if (!h->use_graph) drop_graphs(h);
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "split_max_fronts")) {
     h->split_max_fronts = (int)value;
+    drop_graphs(h);
     h->have_plan = false;
     h->factored = false;
     return HIPFACT_OK;
@@ -1063,7 +1185,8 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
-  INFO("num_solve", h->num_solve) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
+  INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
+  INFO("use_graph", h->use_graph) INFO("num_graphs", h->graphs.size()) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
   INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
   INFO("rows_total", P.sn_rows.size()) INFO("ent_fused", h->ent_fused) INFO("ent_split", h->ent_split)
   INFO("rows_fused", h->rows_fused) INFO("rows_split", h->rows_split)

@@ -92,6 +92,15 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// broadcast of a double from a compile-time-known lane: two v_readlane_b32
+// (scalar path, a few cycles) instead of a ds_bpermute round trip through LDS
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // 1/d to ~1 ulp without the IEEE division sequence: hardware estimate plus two
 // Newton steps.  Sits on the sequential pivot chain of the diagonal blocks.
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -128,11 +137,15 @@ __device__ __forceinline__ FrontCtx make_ctx(const SnDesc& S, double* L, double*
   return c;
 }
 
-// ---- phase A (any block size; no LDS).  Fronts without children are not
-// assembled at all: their Schur update is written in assign mode (phase D).
+// ---- phase A (any block size).  Fronts without children are not assembled at
+// all: their Schur update is written in assign mode (phase D).  `relbuf` is an
+// LDS int array of max(u_child) entries: the child's relative indices are staged
+// once, so that the class test and the scatter addresses cost no dependent
+// global round trips.
 __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c, const SnDesc* __restrict__ sn,
                                              const double* __restrict__ U, const int* __restrict__ rel,
-                                             const int* __restrict__ child_idx, int part, int nparts) {
+                                             const int* __restrict__ child_idx, int part, int nparts,
+                                             int* relbuf) {
   if (S.child_begin == S.child_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
@@ -143,14 +156,16 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
     double* colp = c.Us + (long long)jj * u;
     for (int i = jj + lane; i < u; i += 64) colp[i] = 0.0;
   }
-  __syncthreads();
   for (int ci = S.child_begin; ci < S.child_end; ++ci) {
     const SnDesc Cd = sn[child_idx[ci]];
     const int uc = Cd.r - Cd.w;
     const double* __restrict__ Uc = U + Cd.Uoff;
     const int* __restrict__ rc = rel + Cd.reloff;
+    __syncthreads();  // zeroing / previous child finished; relbuf free
+    for (int a = tid; a < uc; a += blockDim.x) relbuf[a] = rc[a];
+    __syncthreads();
     for (int b = wave; b < uc; b += nw) {
-      const int tb = rc[b];
+      const int tb = relbuf[b];
       if (nparts > 1 && (tb % nparts) != part) continue;
       const double* __restrict__ col = Uc + (long long)b * uc;
       double* dst = (tb < w) ? c.P + (long long)tb * r : c.Us + (long long)(tb - w) * u - w;
@@ -160,17 +175,15 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int a = a0 + lane + 64 * q;
-          t[q] = (a < uc) ? rc[a] : -1;
+          t[q] = (a < uc) ? relbuf[a] : -1;
           v[q] = (a < uc) ? col[a] : 0.0;
+          o[q] = (a < uc) ? dst[t[q]] : 0.0;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (t[q] >= 0) ? dst[t[q]] : 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (t[q] >= 0) dst[t[q]] = o[q] + v[q];
       }
     }
-    __syncthreads();
   }
 }
 
@@ -207,6 +220,8 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     // lane (i = li, q = lk) owns A[i][4q..4q+3] and X[i][4q..4q+3].
     if (wave == 0 && !(phases & 32)) {
       double a[4], x[4];
+      double dmine = 1.0;  // pivot of column li (kept by the lanes with lk == 0)
+      int nzero = 0, nneg = 0;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
@@ -216,30 +231,32 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       for (int k = 0; k < 16; ++k) {
         const int qk = k >> 2, kr = k & 3;
         const double ck_i = __shfl(a[kr], (qk << 4) | li, 64);  // A[i][k]
-        double d = __shfl(a[kr], (qk << 4) | k, 64);            // A[k][k]
-        if (d == 0.0 || !(fabs(d) <= 1.7e308)) {
-          if (lane == 0) atomicAdd(&info[INFO_ZERO_PIVOT], 1);
-          d = 1.0;
-        }
-        if (lane == 0) {
-          dd[k0 + k] = d;
-          if (d < 0.0) atomicAdd(&info[INFO_NEG_PIVOT], 1);
-        }
+        double d = readlane_f64(a[kr], (qk << 4) | k);          // A[k][k] (uniform source lane)
+        const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);   // exactly singular or non-finite
+        nzero += bad ? 1 : 0;
+        d = bad ? 1.0 : d;
+        nneg += (d < 0.0) ? 1 : 0;
+        dmine = (li == k) ? d : dmine;
         const double l_ik = (li > k) ? ck_i * fast_rcp(d) : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const double xk = __shfl(x[cc], (lk << 4) | k, 64);  // X[k][4q+c]
-          x[cc] -= l_ik * xk;
-        }
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int j = 4 * lk + cc;
           const double ck_j = __shfl(a[kr], (qk << 4) | j, 64);  // A[j][k]
-          if (j > k) a[cc] -= l_ik * ck_j;
+          a[cc] = (j > k) ? fma(-l_ik, ck_j, a[cc]) : a[cc];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const double xk = __shfl(x[cc], (lk << 4) | k, 64);  // X[k][4q+c]
+          x[cc] = fma(-l_ik, xk, x[cc]);
         }
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
+      if (lk == 0) dd[k0 + li] = dmine;
+      if (lane == 0 && (nzero | nneg)) {
+        if (nzero) atomicAdd(&info[INFO_ZERO_PIVOT], nzero);
+        if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);
+      }
     }
     __syncthreads();
     // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
@@ -546,9 +563,10 @@ __global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restric
                                                        int nparts, double* __restrict__ L, double* __restrict__ U,
                                                        const int* __restrict__ rel,
                                                        const int* __restrict__ child_idx) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const SnDesc S = sn[items[2 * blockIdx.x]];
   FrontCtx c = make_ctx(S, L, U, nullptr);
-  dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts);
+  dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts, reinterpret_cast<int*>(lds));
 }
 
 __global__ __launch_bounds__(FB) void k_front_pivot(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
@@ -880,6 +898,35 @@ __global__ __launch_bounds__(FB) void k_axpy(long long n, double a, const double
                                              double* __restrict__ y) {
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
     y[i] += a * x[i];
+}
+
+// out[0] = max |r_i|, out[1] = max |b_i|  (single block; decides whether a
+// refinement step is needed)
+__global__ __launch_bounds__(1024) void k_norms(int n, const double* __restrict__ r, const double* __restrict__ b,
+                                                double* __restrict__ out) {
+  __shared__ double sr[1024], sb[1024];
+  double mr = 0.0, mb = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double vr = fabs(r[i]), vb = fabs(b[i]);
+    // NaN-propagating max: a non-finite residual must trigger the error path
+    mr = (vr > mr || vr != vr) ? vr : mr;
+    mb = fmax(mb, vb);
+  }
+  sr[threadIdx.x] = mr;
+  sb[threadIdx.x] = mb;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double a = sr[threadIdx.x], c = sr[threadIdx.x + o];
+      sr[threadIdx.x] = (c > a || c != c) ? c : a;
+      sb[threadIdx.x] = fmax(sb[threadIdx.x], sb[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sr[0];
+    out[1] = sb[0];
+  }
 }
 
 __global__ __launch_bounds__(FB) void k_scatter(long long n, const int* __restrict__ idx,

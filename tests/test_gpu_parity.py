@@ -355,3 +355,43 @@ def test_full_size_properties(fact, workload):
     fact.solve(SleqpVec.from_raw(rhs))
     x = fact.solution_raw(0, n)
     assert np.abs(A @ x - rhs[n:]).max() <= 1e-9 * max(1.0, np.abs(x).max()) * np.abs(A).sum(axis=1).max()
+
+
+def test_adaptive_refinement_and_graphs(fact):
+    """Refinement runs only when the residual asks for it; graph replay and direct launches agree bitwise."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(800, 400, "b", 0.0, 8)
+    N, kc, kr, kd = oracle.fill_aug_jac(800, 400, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    b = np.random.default_rng(2).standard_normal(N)
+    outs = {}
+    for graph in (1, 0):
+        fact.set_option("use_graph", graph)
+        fact.set_option("refine_adaptive", 1)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        for _ in range(3):  # first call captures, later calls replay
+            fact.solve(b)
+        outs[graph] = fact.solution_raw(0, N)
+        assert scaled_residual(K, outs[graph], b) <= RESID_TOL
+    assert np.array_equal(outs[0], outs[1])
+    assert fact.info("num_graphs") == 0
+    fact.set_option("use_graph", 1)
+    # a tolerance nobody can meet forces the correction pass; a loose one suppresses it
+    n0 = fact.info("num_refined")
+    fact.set_option("refine_tol", 0.0)
+    fact.solve(b)
+    assert fact.info("num_refined") == n0 + 1
+    z_ref = fact.solution_raw(0, N)
+    fact.set_option("refine_tol", 1.0)
+    fact.solve(b)
+    assert fact.info("num_refined") == n0 + 1
+    assert rel_err(fact.solution_raw(0, N), z_ref) <= 1e-10
+    # badly scaled rows: the plain solve loses accuracy, the residual check brings it back
+    Jb = sp.csc_matrix(sp.diags(np.logspace(0, 5, 400)) @ J)
+    N2, c2, r2, d2 = oracle.fill_aug_jac(800, 400, Jb.indptr, Jb.indices, Jb.data, vi, ci)
+    K2 = synth.kkt_full_matrix(N2, c2, r2, d2)
+    fact.set_option("refine_tol", 5e-13)
+    fact.set_matrix(SleqpMat(N2, N2, c2, r2, d2))
+    fact.solve(b)
+    assert scaled_residual(K2, fact.solution_raw(0, N2), b) <= RESID_TOL
