@@ -123,7 +123,7 @@ struct hipfact_handle {
   };
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
-  int split_max_fronts = 160;
+  int split_max_fronts = 1 << 30;
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
@@ -380,8 +380,8 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_corr.ensure(nb));
   HCHECK(h, h->d_info.ensure(INFO_WORDS * sizeof(int)));
   HCHECK(h, h->d_minmax.ensure(2 * 64 * sizeof(double)));
-  HCHECK(h, h->d_norms.ensure(2 * sizeof(double)));
-  HCHECK(h, h->h_norms.ensure(2 * sizeof(double)));
+  HCHECK(h, h->d_norms.ensure(2 * sizeof(double) * 4096));
+  HCHECK(h, h->h_norms.ensure(2 * sizeof(double) * 4096));
   HCHECK(h, h->h_info.ensure(INFO_WORDS * sizeof(int) + 2 * 64 * sizeof(double)));
   return HIPFACT_OK;
 }
@@ -501,16 +501,17 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
   }
 }
 
-static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res) {
+static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool norms = false) {
+  double* nptr = norms ? h->d_norms.as<double>() : nullptr;
   const Plan& P = h->plan;
   if (P.saddle) {
     LAUNCH(PC_RESID, k_residual_saddle, dim3(nblocks(P.N)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
-                       h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res);
+                       h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res, nptr);
   } else {
     LAUNCH(PC_RESID, k_residual_sym, dim3(nblocks(P.N)), dim3(FB), 0, P.N, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(),
-                       h->d_Tsrc.as<int>(), b, z, res);
+                       h->d_Tsrc.as<int>(), b, z, res, nptr);
   }
 }
 
@@ -569,11 +570,10 @@ static int solve_first_enqueue(hipfact_handle* h, const double* b, double* z) {
   }
   solve_once_async(h, bb, z);
   if (h->refine_steps > 0) {
-    residual_async(h, bb, z, h->d_res.as<double>());
-    if (h->refine_adaptive) {
-      LAUNCH(PC_AXPY, k_norms, dim3(1), dim3(1024), 0, P.N, h->d_res.as<double>(), bb, h->d_norms.as<double>());
-      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    }
+    residual_async(h, bb, z, h->d_res.as<double>(), h->refine_adaptive);
+    if (h->refine_adaptive)
+      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double) * nblocks(P.N), hipMemcpyDeviceToHost,
+                               h->stream));
   }
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;
@@ -603,7 +603,12 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
     bool correct = true;
     if (h->refine_adaptive) {
       HCHECK(h, hipStreamSynchronize(h->stream));
-      const double rn = h->h_norms.as<double>()[0], bn = h->h_norms.as<double>()[1];
+      double rn = 0.0, bn = 0.0;
+      const double* part = h->h_norms.as<double>();
+      for (int q = 0, nq = nblocks(P.N); q < nq; ++q) {
+        rn = (part[2 * q] > rn || part[2 * q] != part[2 * q]) ? part[2 * q] : rn;
+        bn = std::max(bn, part[2 * q + 1]);
+      }
       correct = !(rn <= h->refine_tol * bn);  // also true for NaN
     }
     if (correct) {
@@ -703,6 +708,8 @@ int hipfact_create(hipfact_handle** out, int device) {
     return HIPFACT_EDEVICE;
   }
   if (const char* s = getenv("HIPFACT_REFINE")) h->refine_steps = atoi(s);
+  if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
+  if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
   *out = h;
   return HIPFACT_OK;
 }

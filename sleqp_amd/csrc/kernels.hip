@@ -854,28 +854,66 @@ __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __rest
   }
 }
 
+// max-norm partials for the refinement check: one (max |res|, max |b|) pair per
+// block, reduced on the host after the (tiny) copy back; no atomics, no extra
+// kernel.  A NaN residual propagates (it must force the correction / error path).
+__device__ __forceinline__ void norms_store(double r, double b, double* __restrict__ norms) {
+  __shared__ double sr[FB / 64], sb[FB / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double vr = __shfl_down(r, o, 64), vb = __shfl_down(b, o, 64);
+    r = (vr > r || vr != vr) ? vr : r;
+    b = fmax(b, vb);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sr[threadIdx.x >> 6] = r;
+    sb[threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < FB / 64; ++q) {
+      r = (sr[q] > r || sr[q] != sr[q]) ? sr[q] : r;
+      b = fmax(b, sb[q]);
+    }
+    norms[2 * blockIdx.x] = r;
+    norms[2 * blockIdx.x + 1] = b;
+  }
+}
+
 // res = b - K z for the saddle matrix (columns < n of the lower CSC hold I and A).
 __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int* __restrict__ Kp,
                                                         const int* __restrict__ Ki, const double* __restrict__ Kval,
                                                         const int* __restrict__ Ar_ptr, const int* __restrict__ Ar_col,
                                                         const double* __restrict__ Ar_val,
                                                         const int* __restrict__ perm, const double* __restrict__ b,
-                                                        const double* __restrict__ z, double* __restrict__ res) {
-  for (int j = blockIdx.x * FB + threadIdx.x; j < n + m; j += gridDim.x * FB) {
+                                                        const double* __restrict__ z, double* __restrict__ res,
+                                                        double* __restrict__ norms) {
+  double mr = 0.0, mb = 0.0;
+  const int total = n + m;
+  const int iters = (total + gridDim.x * FB - 1) / (gridDim.x * FB);
+  for (int it = 0; it < iters; ++it) {  // uniform trip count: the wave reduction below needs all lanes
+    const int j = (it * gridDim.x + blockIdx.x) * FB + threadIdx.x;
     if (j < n) {
-      double s = b[j];
+      const double bj = b[j];
+      double s = bj;
       const int e1 = Kp[j + 1];
       for (int e = Kp[j]; e < e1; ++e) s -= Kval[e] * z[Ki[e]];
       res[j] = s;
-    } else {
+      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
+      mb = fmax(mb, fabs(bj));
+    } else if (j < total) {
       const int k = j - n;
       const int i = n + perm[k];
-      double s = b[i];
+      const double bi = b[i];
+      double s = bi;
       const int p1 = Ar_ptr[k + 1];
       for (int p = Ar_ptr[k]; p < p1; ++p) s -= Ar_val[p] * z[Ar_col[p]];
       res[i] = s;
+      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
+      mb = fmax(mb, fabs(bi));
     }
   }
+  if (norms) norms_store(mr, mb, norms);
 }
 
 // Generic mode residual: res = b - (L + L^T - diag) z with L lower CSC and its
@@ -884,49 +922,30 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
                                                      const double* __restrict__ Kval, const int* __restrict__ Tp,
                                                      const int* __restrict__ Ti, const int* __restrict__ Tsrc,
                                                      const double* __restrict__ b, const double* __restrict__ z,
-                                                     double* __restrict__ res) {
-  for (int j = blockIdx.x * FB + threadIdx.x; j < N; j += gridDim.x * FB) {
-    double s = b[j];
-    for (int e = Kp[j]; e < Kp[j + 1]; ++e) s -= Kval[e] * z[Ki[e]];  // column j: rows >= j
-    for (int p = Tp[j]; p < Tp[j + 1]; ++p)                            // row j: columns < j
-      if (Ti[p] != j) s -= Kval[Tsrc[p]] * z[Ti[p]];
-    res[j] = s;
+                                                     double* __restrict__ res,
+                                                     double* __restrict__ norms) {
+  double mr = 0.0, mb = 0.0;
+  const int iters = (N + gridDim.x * FB - 1) / (gridDim.x * FB);
+  for (int it = 0; it < iters; ++it) {
+    const int j = (it * gridDim.x + blockIdx.x) * FB + threadIdx.x;
+    if (j < N) {
+      const double bj = b[j];
+      double s = bj;
+      for (int e = Kp[j]; e < Kp[j + 1]; ++e) s -= Kval[e] * z[Ki[e]];  // column j: rows >= j
+      for (int p = Tp[j]; p < Tp[j + 1]; ++p)                            // row j: columns < j
+        if (Ti[p] != j) s -= Kval[Tsrc[p]] * z[Ti[p]];
+      res[j] = s;
+      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
+      mb = fmax(mb, fabs(bj));
+    }
   }
+  if (norms) norms_store(mr, mb, norms);
 }
 
 __global__ __launch_bounds__(FB) void k_axpy(long long n, double a, const double* __restrict__ x,
                                              double* __restrict__ y) {
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
     y[i] += a * x[i];
-}
-
-// out[0] = max |r_i|, out[1] = max |b_i|  (single block; decides whether a
-// refinement step is needed)
-__global__ __launch_bounds__(1024) void k_norms(int n, const double* __restrict__ r, const double* __restrict__ b,
-                                                double* __restrict__ out) {
-  __shared__ double sr[1024], sb[1024];
-  double mr = 0.0, mb = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const double vr = fabs(r[i]), vb = fabs(b[i]);
-    // NaN-propagating max: a non-finite residual must trigger the error path
-    mr = (vr > mr || vr != vr) ? vr : mr;
-    mb = fmax(mb, vb);
-  }
-  sr[threadIdx.x] = mr;
-  sb[threadIdx.x] = mb;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const double a = sr[threadIdx.x], c = sr[threadIdx.x + o];
-      sr[threadIdx.x] = (c > a || c != c) ? c : a;
-      sb[threadIdx.x] = fmax(sb[threadIdx.x], sb[threadIdx.x + o]);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out[0] = sr[0];
-    out[1] = sb[0];
-  }
 }
 
 __global__ __launch_bounds__(FB) void k_scatter(long long n, const int* __restrict__ idx,

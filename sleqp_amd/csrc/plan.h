@@ -28,9 +28,11 @@ struct PlanParams {
   int nd_leaf = 0;         // 0 = automatic
   double nd_sep_frac = 0.2;
   int wmax = 128;          // widest supernode (diagonal block is LDS resident)
-  double relax_small = 0.5;   // allowed explicit-zero fraction, merged width <= 32
-  double relax_mid = 0.25;    // ... <= 64
-  double relax_big = 0.10;    // ... wider
+  // allowed explicit-zero fraction when merging a child into its parent: generous,
+  // because every tree level costs a fixed ~0.15 ms of dependent kernel latency
+  double relax_small = 0.6;   // merged width <= 32
+  double relax_mid = 0.4;     // ... <= 64
+  double relax_big = 0.3;     // ... wider
   bool force_generic = false;
 };
 
