@@ -290,7 +290,7 @@ static int upload_plan(hipfact_handle* h) {
     }
     const size_t wp = (size_t)((mw + 15) & ~15);
     const size_t needB = wp * (wp + 1) + 16 * (wp + 1);
-    const size_t needD = (size_t)128 * mw;
+    const size_t needD = (size_t)128 * 64;  // two 64 x 64 operand strips
     li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
     li.lds_pivot = (wp + needB) * sizeof(double);
     li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double);

@@ -398,15 +398,16 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
 }
 
 // ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
-// rows at a time: the B operand streams from the panel (16 consecutive rows per
-// k-step), the A operand is X from LDS; results are stored row-contiguous.
-// Row blocks blk, blk + nblk_stride, ... (64 rows each).
+// rows: the B operand streams from the panel (16 consecutive rows per k-step),
+// the A operand is X = inv(L11), read from LDS (fused kernel) or straight from
+// the finished panel top in L2 (split kernel: no LDS, no barrier, full
+// occupancy); results are stored row-contiguous.  Row blocks blk, blk + stride.
+template <bool X_IN_LDS>
 __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
   const double* A = c.A;
-  const double* dd = c.dd;
   double* __restrict__ P = c.P;
   for (int R0 = w + 64 * blk + 16 * wave; R0 < r; R0 += 64 * blk_stride) {
     const bool rok = (R0 + li) < r;
@@ -420,6 +421,7 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
       const int col = 4 * s + lk;
       pv[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
     }
+#pragma unroll 1
     for (int tt = 0; tt < nbk; ++tt) {
       if (tt + 1 < nbk) {
 #pragma unroll
@@ -428,15 +430,33 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
           pn[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
         }
       }
+      if (X_IN_LDS) {
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct)
-        if (ct >= tt && ct < nbk) {
+        for (int ct = 0; ct < 8; ++ct)
+          if (ct >= tt && ct < nbk) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
-            acc[ct] = MFMA_F64(xv, pv[s], acc[ct]);
+            for (int s = 0; s < 4; ++s) {
+              const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
+              acc[ct] = MFMA_F64(xv, pv[s], acc[ct]);
+            }
           }
-        }
+      } else {
+        // X(i, k) for i > k from the panel top, unit diagonal, zero above
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+          if (ct >= tt && ct < nbk) {
+            double xv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int i = 16 * ct + li, k = 16 * tt + 4 * s + lk;
+              double v = (i == k) ? 1.0 : 0.0;
+              if (i < w && i > k) v = P[i + (long long)k * r];
+              xv[s] = v;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[ct] = MFMA_F64(xv[s], pv[s], acc[ct]);
+          }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) pv[s] = pn[s];
     }
@@ -447,7 +467,10 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int col = 16 * ct + lk + 4 * q;
-            if (col < w) P[(R0 + li) + (long long)col * r] = acc[ct][q] / dd[col];
+            if (col < w) {
+              const double dcol = X_IN_LDS ? c.dd[col] : P[col + (long long)col * r];
+              P[(R0 + li) + (long long)col * r] = acc[ct][q] / dcol;
+            }
           }
         }
     }
@@ -455,66 +478,71 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 }
 
 // ---- phase D: one 64 x 64 tile (I, J) of U_s -= L21 D L21^T.  Operand strips
-// (64 rows x w, k-major) staged in LDS; strip I is reused while `stage_i` is false.
-__device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool stage_i,
-                                               bool assign) {
+// (64 rows x 64 pivots per chunk, k-major) staged in LDS: 64 KB per workgroup, so
+// that two workgroups share a CU and hide each other's staging latency.
+constexpr int KC = 64;
+__device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, u = c.u;
   const double* __restrict__ P21 = c.P + w;
-  __syncthreads();  // previous tile has finished reading the strips
-  {
-    const int i = tid & 63;
-    const bool iok = (64 * I + i) < u, jok = (64 * J + i) < u;
-    const double* __restrict__ pi = P21 + 64 * I + i;
-    const double* __restrict__ pj = P21 + 64 * J + i;
-    for (int kk = tid >> 6; kk < w; kk += 32) {
-      double vi[8], vj[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = kk + 4 * q;
-        vi[q] = (stage_i && iok && k < w) ? pi[(long long)k * r] : 0.0;
-        vj[q] = (jok && k < w) ? pj[(long long)k * r] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = kk + 4 * q;
-        if (k < w) {
-          if (stage_i) SI[k * 64 + i] = vi[q];
-          SJ[k * 64 + i] = vj[q] * c.dd[k];
-        }
-      }
-    }
-  }
-  __syncthreads();
   const int wi = wave & 1, wj = wave >> 1;
-  if (I == J && wi < wj) return;  // block above the diagonal
+  const bool idle = (I == J && wi < wj);  // block above the diagonal
   const int i0 = 32 * wi, j0 = 32 * wj;
   d4_t acc[2][2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  const int w4 = w & ~3;
-  for (int k0 = 0; k0 < w4; k0 += 4) {
-    const int kk = (k0 + lk) * 64;
-    const double a0 = SJ[kk + j0 + li], a1 = SJ[kk + j0 + 16 + li];
-    const double b0 = SI[kk + i0 + li], b1 = SI[kk + i0 + 16 + li];
-    acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
-    acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
-    acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
-    acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+  const int si = tid & 63;
+  const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
+  const double* __restrict__ pi = P21 + 64 * I + si;
+  const double* __restrict__ pj = P21 + 64 * J + si;
+  for (int kc0 = 0; kc0 < w; kc0 += KC) {
+    const int kcn = min(KC, w - kc0);
+    __syncthreads();  // previous chunk / tile has finished reading the strips
+    for (int kk = tid >> 6; kk < kcn; kk += 32) {
+      double vi[8], vj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        vi[q] = (iok && k < kcn) ? pi[(long long)(kc0 + k) * r] : 0.0;
+        vj[q] = (jok && k < kcn) ? pj[(long long)(kc0 + k) * r] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kk + 4 * q;
+        if (k < kcn) {
+          SI[k * 64 + si] = vi[q];
+          SJ[k * 64 + si] = vj[q] * c.dd[kc0 + k];
+        }
+      }
+    }
+    __syncthreads();
+    if (!idle) {
+      const int k4 = kcn & ~3;
+      for (int k0 = 0; k0 < k4; k0 += 4) {
+        const int kk = (k0 + lk) * 64;
+        const double a0 = SJ[kk + j0 + li], a1 = SJ[kk + j0 + 16 + li];
+        const double b0 = SI[kk + i0 + li], b1 = SI[kk + i0 + 16 + li];
+        acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+        acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
+        acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
+        acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+      }
+      if (k4 < kcn) {
+        const bool kok = (k4 + lk) < kcn;
+        const int kk = (k4 + lk) * 64;
+        const double a0 = kok ? SJ[kk + j0 + li] : 0.0, a1 = kok ? SJ[kk + j0 + 16 + li] : 0.0;
+        const double b0 = kok ? SI[kk + i0 + li] : 0.0, b1 = kok ? SI[kk + i0 + 16 + li] : 0.0;
+        acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+        acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
+        acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
+        acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+      }
+    }
   }
-  if (w4 < w) {
-    const bool kok = (w4 + lk) < w;
-    const int kk = (w4 + lk) * 64;
-    const double a0 = kok ? SJ[kk + j0 + li] : 0.0, a1 = kok ? SJ[kk + j0 + 16 + li] : 0.0;
-    const double b0 = kok ? SI[kk + i0 + li] : 0.0, b1 = kok ? SI[kk + i0 + 16 + li] : 0.0;
-    acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
-    acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
-    acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
-    acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
-  }
+  if (idle) return;
   // acc[x][y][q] = update of U(i = 64 I + i0 + 16 y + li, j = 64 J + j0 + 16 x + lk + 4 q)
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -547,14 +575,14 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
   dev_pivot_block(c, info, phases);
   dev_store_pivot_block(c);
   if (!(phases & 4)) return;
-  dev_panel_solve(c, 0, 1);
+  dev_panel_solve<true>(c, 0, 1);
   __syncthreads();
   if (c.u > 0 && (phases & 8)) {
     double* SI = c.A;
-    double* SJ = c.A + 64 * c.w;
+    double* SJ = c.A + 64 * KC;
     const int nt = (c.u + 63) >> 6;
     for (int I = 0; I < nt; ++I)
-      for (int J = 0; J <= I; ++J) dev_schur_tile(c, SI, SJ, I, J, J == 0, S.child_begin == S.child_end);
+      for (int J = 0; J <= I; ++J) dev_schur_tile(c, SI, SJ, I, J, S.child_begin == S.child_end);
   }
 }
 
@@ -585,7 +613,7 @@ __global__ __launch_bounds__(FB) void k_front_panel(const SnDesc* __restrict__ s
   const SnDesc S = sn[items[2 * blockIdx.x]];
   const FrontCtx c = make_ctx(S, L, U, lds);
   dev_load_pivot_block(c, true);
-  dev_panel_solve(c, items[2 * blockIdx.x + 1], 1 << 24);
+  dev_panel_solve<true>(c, items[2 * blockIdx.x + 1], 1 << 24);
 }
 
 // items: supernode, (I << 16) | J
@@ -596,7 +624,7 @@ __global__ __launch_bounds__(FB) void k_front_schur(const SnDesc* __restrict__ s
   const FrontCtx c = make_ctx(S, L, U, lds);
   dev_load_pivot_block(c, false);
   const int ij = items[2 * blockIdx.x + 1];
-  dev_schur_tile(c, c.A, c.A + 64 * c.w, ij >> 16, ij & 0xffff, true, S.child_begin == S.child_end);
+  dev_schur_tile(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.child_begin == S.child_end);
 }
 
 // ---------------------------------------------------------------------------
