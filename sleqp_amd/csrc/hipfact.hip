@@ -485,12 +485,12 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
   if (P.N == 0) return;
   if (P.saddle) {
     if (P.m > 0) {
-      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks(P.m)), dim3(FB), 0, P.m, P.n, h->d_Ar_ptr.as<int>(),
+      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks((long long)P.m * 16)), dim3(FB), 0, P.m, P.n, h->d_Ar_ptr.as<int>(),
                          h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b,
                          h->d_y.as<double>());
       solve_m_async(h);
     }
-    LAUNCH(PC_XUPD, k_x_saddle, dim3(nblocks(P.N)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
+    LAUNCH(PC_XUPD, k_x_saddle, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
                        h->d_Kval.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), h->d_y.as<double>(), b, z);
   } else {
     LAUNCH(PC_PERM, k_gather, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(), b,
@@ -501,15 +501,18 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
   }
 }
 
+// grid of the residual kernels (= number of max-norm partial pairs they write)
+static inline int resid_blocks(const Plan& P) { return P.saddle ? nblocks((long long)P.N * 8, 2048) : nblocks(P.N); }
+
 static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool norms = false) {
   double* nptr = norms ? h->d_norms.as<double>() : nullptr;
   const Plan& P = h->plan;
   if (P.saddle) {
-    LAUNCH(PC_RESID, k_residual_saddle, dim3(nblocks(P.N)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
+    LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
                        h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res, nptr);
   } else {
-    LAUNCH(PC_RESID, k_residual_sym, dim3(nblocks(P.N)), dim3(FB), 0, P.N, h->d_Kp.as<int>(),
+    LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(),
                        h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(),
                        h->d_Tsrc.as<int>(), b, z, res, nptr);
   }
@@ -572,7 +575,7 @@ static int solve_first_enqueue(hipfact_handle* h, const double* b, double* z) {
   if (h->refine_steps > 0) {
     residual_async(h, bb, z, h->d_res.as<double>(), h->refine_adaptive);
     if (h->refine_adaptive)
-      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double) * nblocks(P.N), hipMemcpyDeviceToHost,
+      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double) * resid_blocks(P), hipMemcpyDeviceToHost,
                                h->stream));
   }
   HCHECK(h, hipGetLastError());
@@ -605,7 +608,7 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
       HCHECK(h, hipStreamSynchronize(h->stream));
       double rn = 0.0, bn = 0.0;
       const double* part = h->h_norms.as<double>();
-      for (int q = 0, nq = nblocks(P.N); q < nq; ++q) {
+      for (int q = 0, nq = resid_blocks(P); q < nq; ++q) {
         rn = (part[2 * q] > rn || part[2 * q] != part[2 * q]) ? part[2 * q] : rn;
         bn = std::max(bn, part[2 * q + 1]);
       }

@@ -219,6 +219,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     // S1: wave 0 factors the diagonal block and inverts its unit lower factor.
     // lane (i = li, q = lk) owns A[i][4q..4q+3] and X[i][4q..4q+3].
     if (wave == 0 && !(phases & 32)) {
+      // Cross-lane exchange through a 32-double LDS scratch (column k of A, row k
+      // of X): LDS operations of one wave execute in order, so a write followed by
+      // reads needs no barrier; far fewer instructions than ds_bpermute shuffles.
+      double* colk = Yp;        // 16: A[.][k]   (Yp is free during S1)
+      double* xrow = Yp + 16;   // 16: X[k][.]
       double a[4], x[4];
       double dmine = 1.0;  // pivot of column li (kept by the lanes with lk == 0)
       int nzero = 0, nneg = 0;
@@ -230,9 +235,23 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int qk = k >> 2, kr = k & 3;
-        const double ck_i = __shfl(a[kr], (qk << 4) | li, 64);  // A[i][k]
-        double d = readlane_f64(a[kr], (qk << 4) | k);          // A[k][k] (uniform source lane)
-        const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);   // exactly singular or non-finite
+        if (lk == qk) colk[li] = a[kr];
+        if (li == k) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) xrow[4 * lk + cc] = x[cc];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double ck_i = colk[li];  // A[i][k]
+        double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
+                                                        // reciprocal chain overlaps the LDS round trip
+        double ckj[4], xk[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc
+          xk[cc] = xrow[4 * lk + cc];   // X[k][j]
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);  // exactly singular or non-finite
         nzero += bad ? 1 : 0;
         d = bad ? 1.0 : d;
         nneg += (d < 0.0) ? 1 : 0;
@@ -241,13 +260,8 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int j = 4 * lk + cc;
-          const double ck_j = __shfl(a[kr], (qk << 4) | j, 64);  // A[j][k]
-          a[cc] = (j > k) ? fma(-l_ik, ck_j, a[cc]) : a[cc];
-        }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const double xk = __shfl(x[cc], (lk << 4) | k, 64);  // X[k][4q+c]
-          x[cc] = fma(-l_ik, xk, x[cc]);
+          a[cc] = (j > k) ? fma(-l_ik, ckj[cc], a[cc]) : a[cc];
+          x[cc] = fma(-l_ik, xk[cc], x[cc]);
         }
       }
 #pragma unroll
@@ -853,33 +867,42 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
 // A_p is the CSR of A with rows in pivot order; the x update walks the columns
 // of K itself (its CSC arrays are the CSR of A^T).
 // ---------------------------------------------------------------------------
+// 16 lanes per row (rows of A hold ~20 entries in the headline configuration):
+// consecutive lanes read consecutive entries, fixed shuffle tree => deterministic.
+constexpr int RL = 16;
 __global__ __launch_bounds__(FB) void k_rhs_saddle(int m, int n, const int* __restrict__ Ar_ptr,
                                                    const int* __restrict__ Ar_col, const double* __restrict__ Ar_val,
                                                    const int* __restrict__ perm, const double* __restrict__ b,
                                                    double* __restrict__ t) {
-  for (int k = blockIdx.x * FB + threadIdx.x; k < m; k += gridDim.x * FB) {
+  const int sub = threadIdx.x % RL;
+  const int rpb = FB / RL;
+  for (int k = blockIdx.x * rpb + threadIdx.x / RL; k < m; k += gridDim.x * rpb) {
     double s = 0.0;
     const int p1 = Ar_ptr[k + 1];
-    for (int p = Ar_ptr[k]; p < p1; ++p) s += Ar_val[p] * b[Ar_col[p]];
-    t[k] = s - b[n + perm[k]];
+    for (int p = Ar_ptr[k] + sub; p < p1; p += RL) s += Ar_val[p] * b[Ar_col[p]];
+#pragma unroll
+    for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
+    if (sub == 0) t[k] = s - b[n + perm[k]];
   }
 }
 
+// 8 lanes per column of K (columns hold ~11 entries)
+constexpr int CL = 8;
 __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __restrict__ Kp,
                                                  const double* __restrict__ Kval, const int* __restrict__ Kc_y,
                                                  const int* __restrict__ perm, const double* __restrict__ yp,
                                                  const double* __restrict__ b, double* __restrict__ z) {
-  for (int j = blockIdx.x * FB + threadIdx.x; j < n + m; j += gridDim.x * FB) {
-    if (j < n) {
-      double s = b[j];
-      const int e1 = Kp[j + 1];
-      for (int e = Kp[j] + 1; e < e1; ++e) s -= Kval[e] * yp[Kc_y[e]];
-      z[j] = s;
-    } else {
-      const int k = j - n;
-      z[n + perm[k]] = yp[k];
-    }
+  const int sub = threadIdx.x % CL;
+  const int cpb = FB / CL;
+  for (int j = blockIdx.x * cpb + threadIdx.x / CL; j < n; j += gridDim.x * cpb) {
+    double s = 0.0;
+    const int e1 = Kp[j + 1];
+    for (int e = Kp[j] + 1 + sub; e < e1; e += CL) s += Kval[e] * yp[Kc_y[e]];
+#pragma unroll
+    for (int o = CL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, CL);
+    if (sub == 0) z[j] = b[j] - s;
   }
+  for (int k = blockIdx.x * FB + threadIdx.x; k < m; k += gridDim.x * FB) z[n + perm[k]] = yp[k];
 }
 
 // max-norm partials for the refinement check: one (max |res|, max |b|) pair per
@@ -909,6 +932,8 @@ __device__ __forceinline__ void norms_store(double r, double b, double* __restri
 }
 
 // res = b - K z for the saddle matrix (columns < n of the lower CSC hold I and A).
+// Two sweeps with cooperative lanes (8 per column of K, 16 per row of A), block
+// partial max-norms for the refinement check.
 __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int* __restrict__ Kp,
                                                         const int* __restrict__ Ki, const double* __restrict__ Kval,
                                                         const int* __restrict__ Ar_ptr, const int* __restrict__ Ar_col,
@@ -917,28 +942,49 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
                                                         const double* __restrict__ z, double* __restrict__ res,
                                                         double* __restrict__ norms) {
   double mr = 0.0, mb = 0.0;
-  const int total = n + m;
-  const int iters = (total + gridDim.x * FB - 1) / (gridDim.x * FB);
-  for (int it = 0; it < iters; ++it) {  // uniform trip count: the wave reduction below needs all lanes
-    const int j = (it * gridDim.x + blockIdx.x) * FB + threadIdx.x;
-    if (j < n) {
-      const double bj = b[j];
-      double s = bj;
-      const int e1 = Kp[j + 1];
-      for (int e = Kp[j]; e < e1; ++e) s -= Kval[e] * z[Ki[e]];
-      res[j] = s;
-      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
-      mb = fmax(mb, fabs(bj));
-    } else if (j < total) {
-      const int k = j - n;
-      const int i = n + perm[k];
-      const double bi = b[i];
-      double s = bi;
-      const int p1 = Ar_ptr[k + 1];
-      for (int p = Ar_ptr[k]; p < p1; ++p) s -= Ar_val[p] * z[Ar_col[p]];
-      res[i] = s;
-      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
-      mb = fmax(mb, fabs(bi));
+  {
+    const int sub = threadIdx.x % CL;
+    const int cpb = FB / CL;
+    const int iters = (n + gridDim.x * cpb - 1) / (gridDim.x * cpb);
+    for (int it = 0; it < iters; ++it) {  // uniform trip count (the shuffles need whole groups)
+      const int j = (it * gridDim.x + blockIdx.x) * cpb + threadIdx.x / CL;
+      double s = 0.0;
+      if (j < n) {
+        const int e1 = Kp[j + 1];
+        for (int e = Kp[j] + sub; e < e1; e += CL) s += Kval[e] * z[Ki[e]];
+      }
+#pragma unroll
+      for (int o = CL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, CL);
+      if (sub == 0 && j < n) {
+        const double bj = b[j];
+        const double rj = bj - s;
+        res[j] = rj;
+        mr = (fabs(rj) > mr || rj != rj) ? fabs(rj) : mr;
+        mb = fmax(mb, fabs(bj));
+      }
+    }
+  }
+  {
+    const int sub = threadIdx.x % RL;
+    const int rpb = FB / RL;
+    const int iters = (m + gridDim.x * rpb - 1) / (gridDim.x * rpb);
+    for (int it = 0; it < iters; ++it) {
+      const int k = (it * gridDim.x + blockIdx.x) * rpb + threadIdx.x / RL;
+      double s = 0.0;
+      if (k < m) {
+        const int p1 = Ar_ptr[k + 1];
+        for (int p = Ar_ptr[k] + sub; p < p1; p += RL) s += Ar_val[p] * z[Ar_col[p]];
+      }
+#pragma unroll
+      for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
+      if (sub == 0 && k < m) {
+        const int i = n + perm[k];
+        const double bi = b[i];
+        const double ri = bi - s;
+        res[i] = ri;
+        mr = (fabs(ri) > mr || ri != ri) ? fabs(ri) : mr;
+        mb = fmax(mb, fabs(bi));
+      }
     }
   }
   if (norms) norms_store(mr, mb, norms);
