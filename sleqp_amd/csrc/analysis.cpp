@@ -6,18 +6,38 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "graph.h"
 
 namespace hipfact {
 
 namespace {
+
+// static-partition parallel loop over [0, n): fn(begin, end, thread_index)
+template <class F>
+void parallel_chunks(int n, F fn) {
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int nt = std::max(1, std::min({hw, 32, n / 2048 + 1}));
+  if (nt == 1) {
+    fn(0, n, 0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) {
+    const int b = (int)((long long)n * t / nt), e = (int)((long long)n * (t + 1) / nt);
+    pool.emplace_back([=, &fn] { fn(b, e, t); });
+  }
+  for (auto& th : pool) th.join();
+}
 
 double now_s() {
   using clk = std::chrono::steady_clock;
@@ -250,6 +270,15 @@ void split_wide(std::vector<RawSuper>& sn, int wmax) {
 
 bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const PlanParams& prm_in, Plan& P) {
   const double t0 = now_s();
+  const bool timing = getenv("HIPFACT_TIMING") != nullptr;
+  double tlast = t0;
+  auto tick = [&](const char* what) {
+    if (timing) {
+      const double t = now_s();
+      fprintf(stderr, "[hipfact analysis] %-28s %8.2f ms\n", what, (t - tlast) * 1e3);
+      tlast = t;
+    }
+  };
   PlanParams prm = prm_in;
   if (const char* e = getenv("HIPFACT_ORDERING")) prm.ordering = atoi(e);
   if (const char* e = getenv("HIPFACT_ND_LEAF")) prm.nd_leaf = atoi(e);
@@ -331,21 +360,46 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         ar_src[fill[a]] = e;
         ++fill[a];
       }
-    std::vector<int> mark(m, -1);
-    for (int a = 0; a < m; ++a) {
-      mark[a] = a;
-      for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
-        const int j = ar_col[q];
-        for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
-          const int b = Ki[e] - nx;
-          if (mark[b] != a) {
-            mark[b] = a;
-            g.adj.push_back(b);
+    // S = A A^T: rows are independent (count, prefix, fill; one marker array per thread)
+    std::vector<int64_t> deg(m + 1, 0);
+    parallel_chunks(m, [&](int lo, int hi, int) {
+      std::vector<int> mark(m, -1);
+      for (int a = lo; a < hi; ++a) {
+        mark[a] = a;
+        int64_t c = 0;
+        for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
+          const int j = ar_col[q];
+          for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+            const int b = Ki[e] - nx;
+            if (mark[b] != a) {
+              mark[b] = a;
+              ++c;
+            }
+          }
+        }
+        deg[a + 1] = c;
+      }
+    });
+    for (int a = 0; a < m; ++a) deg[a + 1] += deg[a];
+    g.ptr.assign(deg.begin(), deg.end());
+    g.adj.resize(g.ptr[m]);
+    parallel_chunks(m, [&](int lo, int hi, int) {
+      std::vector<int> mark(m, -1);
+      for (int a = lo; a < hi; ++a) {
+        mark[a] = a;
+        int64_t o = g.ptr[a];
+        for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
+          const int j = ar_col[q];
+          for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+            const int b = Ki[e] - nx;
+            if (mark[b] != a) {
+              mark[b] = a;
+              g.adj[o++] = b;
+            }
           }
         }
       }
-      g.ptr[a + 1] = (int64_t)g.adj.size();
-    }
+    });
   } else {
     std::vector<int64_t> cnt(m + 1, 0);
     for (int j = 0; j < N; ++j)
@@ -366,6 +420,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         }
   }
 
+  tick("validate + graph of M");
   // ---- ordering
   const double t1 = now_s();
   std::vector<int> perm;
@@ -386,6 +441,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   std::vector<int> iperm(m);
   for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
   P.t_order = now_s() - t1;
+  tick("ordering");
 
   // ---- elimination tree, postorder (twice: second time with children sorted
   // by column count so that the heaviest child is adjacent to its parent)
@@ -393,13 +449,17 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   std::vector<int> parent, post, colcount;
   std::vector<RawSuper> sn;
   for (int pass = 0; pass < 2; ++pass) {
-    etree(g, perm, iperm, parent);
+    if (pass == 0) etree(g, perm, iperm, parent);
     postorder(parent, pass == 0 ? nullptr : &colcount, post);
-    std::vector<int> perm2(m);
-    for (int k = 0; k < m; ++k) perm2[k] = perm[post[k]];
+    std::vector<int> perm2(m), inv(m), parent2(m);
+    for (int k = 0; k < m; ++k) {
+      perm2[k] = perm[post[k]];
+      inv[post[k]] = k;
+    }
+    for (int k = 0; k < m; ++k) parent2[inv[k]] = parent[k] < 0 ? -1 : inv[parent[k]];
     perm.swap(perm2);
+    parent.swap(parent2);
     for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
-    etree(g, perm, iperm, parent);
     symbolic(g, perm, iperm, parent, sn, colcount);
   }
   P.nnzL_true = 0;
@@ -408,6 +468,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     P.nnzL_true += colcount[k];
     P.flops += (double)colcount[k] * colcount[k];
   }
+  tick("etree + symbolic (2 passes)");
   amalgamate(sn, m, prm);
   split_wide(sn, prm.wmax);
 
@@ -509,53 +570,64 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     }
   }
 
+  tick("supernode arrays + rel");
   // ---- M pattern in pivot order with target offsets into the L arena
   P.Mp.assign(m + 1, 0);
-  for (int k = 0; k < m; ++k) {
-    const int v = perm[k];
-    int64_t c = 1;
-    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
-      if (iperm[g.adj[q]] > k) ++c;
-    P.Mp[k + 1] = P.Mp[k] + c;
-  }
+  parallel_chunks(m, [&](int lo, int hi, int) {
+    for (int k = lo; k < hi; ++k) {
+      const int v = perm[k];
+      int64_t c = 1;
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
+        if (iperm[g.adj[q]] > k) ++c;
+      P.Mp[k + 1] = c;
+    }
+  });
+  for (int k = 0; k < m; ++k) P.Mp[k + 1] += P.Mp[k];
   P.Mi.resize(P.Mp[m]);
   P.Mtarget.resize(P.Mp[m]);
   {
-    std::vector<int> pos(m, -1);
-    for (int s = 0; s < ns; ++s) {
-      const std::vector<int>& rs = sn[s].rows;
-      const int r = (int)rs.size();
-      for (int t = 0; t < r; ++t) pos[rs[t]] = t;
-      for (int k = sn[s].c0; k < sn[s].c0 + sn[s].w; ++k) {
-        const int v = perm[k];
-        int64_t o = P.Mp[k];
-        P.Mi[o++] = k;
-        for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
-          const int i = iperm[g.adj[q]];
-          if (i > k) P.Mi[o++] = i;
-        }
-        std::sort(P.Mi.begin() + P.Mp[k] + 1, P.Mi.begin() + P.Mp[k + 1]);
-        for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) {
-          const int t = pos[P.Mi[e]];
-          if (t < 0) {
-            P.error = "internal: matrix entry outside front";
-            return false;
+    std::atomic<bool> bad{false};
+    parallel_chunks(ns, [&](int lo, int hi, int) {
+      std::vector<int> pos(m, -1);
+      for (int s = lo; s < hi; ++s) {
+        const std::vector<int>& rs = sn[s].rows;
+        const int r = (int)rs.size();
+        for (int t = 0; t < r; ++t) pos[rs[t]] = t;
+        for (int k = sn[s].c0; k < sn[s].c0 + sn[s].w; ++k) {
+          const int v = perm[k];
+          int64_t o = P.Mp[k];
+          P.Mi[o++] = k;
+          for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+            const int i = iperm[g.adj[q]];
+            if (i > k) P.Mi[o++] = i;
           }
-          P.Mtarget[e] = P.sn_Loff[s] + t + (int64_t)(k - sn[s].c0) * r;
+          std::sort(P.Mi.begin() + P.Mp[k] + 1, P.Mi.begin() + P.Mp[k + 1]);
+          for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) {
+            const int t = pos[P.Mi[e]];
+            if (t < 0) {
+              bad = true;
+              continue;
+            }
+            P.Mtarget[e] = P.sn_Loff[s] + t + (int64_t)(k - sn[s].c0) * r;
+          }
         }
+        for (int t = 0; t < r; ++t) pos[rs[t]] = -1;
       }
-      for (int t = 0; t < r; ++t) pos[rs[t]] = -1;
+    });
+    if (bad) {
+      P.error = "internal: matrix entry outside front";
+      return false;
     }
   }
 
+  tick("M pattern + targets");
   // ---- value sources
   if (saddle) {
     // product lists: M(i,k) = sum_j A(perm[i], j) A(perm[k], j)
     P.prod_ptr.assign(P.Mp[m] + 1, 0);
-    std::vector<int> pos(m, -1);
-    // pass 1: counts
+    // pass 0 counts, pass 1 fills; columns are independent (one pos array per thread)
+    std::vector<int64_t> fill;
     for (int pass = 0; pass < 2; ++pass) {
-      std::vector<int64_t> fill;
       if (pass == 1) {
         for (int64_t e = 0; e < P.Mp[m]; ++e) P.prod_ptr[e + 1] += P.prod_ptr[e];
         P.nprod = P.prod_ptr[P.Mp[m]];
@@ -567,26 +639,29 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         P.prod_b.resize(P.nprod);
         fill.assign(P.prod_ptr.begin(), P.prod_ptr.end() - 1);
       }
-      for (int k = 0; k < m; ++k) {
-        for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) pos[P.Mi[e]] = (int)(e - P.Mp[k]);
-        const int b = perm[k];
-        for (int q = ar_ptr[b]; q < ar_ptr[b + 1]; ++q) {
-          const int j = ar_col[q];
-          const int eb = ar_src[q];
-          for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
-            const int i = iperm[Ki[e] - nx];
-            if (i < k) continue;
-            const int64_t me = P.Mp[k] + pos[i];
-            if (pass == 0)
-              ++P.prod_ptr[me + 1];
-            else {
-              P.prod_a[fill[me]] = e;
-              P.prod_b[fill[me]] = eb;
-              ++fill[me];
+      parallel_chunks(m, [&](int lo, int hi, int) {
+        std::vector<int> pos(m, -1);
+        for (int k = lo; k < hi; ++k) {
+          for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) pos[P.Mi[e]] = (int)(e - P.Mp[k]);
+          const int b = perm[k];
+          for (int q = ar_ptr[b]; q < ar_ptr[b + 1]; ++q) {
+            const int j = ar_col[q];
+            const int eb = ar_src[q];
+            for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+              const int i = iperm[Ki[e] - nx];
+              if (i < k) continue;
+              const int64_t me = P.Mp[k] + pos[i];
+              if (pass == 0)
+                ++P.prod_ptr[me + 1];
+              else {
+                P.prod_a[fill[me]] = e;
+                P.prod_b[fill[me]] = eb;
+                ++fill[me];
+              }
             }
           }
         }
-      }
+      });
     }
     // SpMV structures
     P.Ar_ptr.assign(m + 1, 0);
@@ -618,6 +693,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         P.src[it - P.Mi.begin()] = e;
       }
   }
+  tick("value sources (product lists)");
   P.t_symbolic = now_s() - t2;
   P.t_total = now_s() - t0;
   return true;

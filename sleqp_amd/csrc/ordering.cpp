@@ -13,9 +13,11 @@
 #include "graph.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstdint>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 namespace hipfact {
@@ -242,26 +244,42 @@ struct NDState {
   std::vector<int> local;  // global -> local index for leaf subgraphs
   int stamp = 0;
   std::vector<int>& perm;
+  // Leaf subgraphs are independent: the dissection only records them (vertex
+  // list + the slice of the permutation they own, marked in leaf_id[]) and they
+  // are ordered by minimum degree in parallel afterwards.
+  struct LeafTask {
+    std::vector<int> verts;
+    int off;
+  };
+  std::vector<LeafTask> leaves;
+  std::vector<int> leaf_id;
   NDState(const Graph& g_, const NDParams& p, std::vector<int>& out)
-      : g(g_), prm(p), inset(g_.n, -1), level(g_.n, -1), local(g_.n, -1), perm(out) {}
+      : g(g_), prm(p), inset(g_.n, -1), level(g_.n, -1), local(g_.n, -1), perm(out), leaf_id(g_.n, -1) {}
 
   void leaf(const std::vector<int>& verts) {
-    const int k = (int)verts.size();
-    if (k <= 2) {
-      for (int v : verts) perm.push_back(v);
-      return;
+    const int off = (int)perm.size();
+    const int id = (int)leaves.size();
+    for (int v : verts) {
+      perm.push_back(v);  // placeholder order, replaced by run_leaves()
+      leaf_id[v] = id;
     }
+    if (verts.size() > 2) leaves.push_back({verts, off});
+    else leaves.push_back({std::vector<int>(), off});
+  }
+
+  void order_leaf(const LeafTask& task, int id) {
+    const std::vector<int>& verts = task.verts;
+    const int k = (int)verts.size();
+    if (k <= 2) return;
     for (int t = 0; t < k; ++t) local[verts[t]] = t;
     Graph sub;
     sub.n = k;
     sub.ptr.assign(k + 1, 0);
-    const int id = ++stamp;
-    for (int v : verts) inset[v] = id;
     for (int t = 0; t < k; ++t) {
       const int v = verts[t];
       int64_t c = 0;
       for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
-        if (inset[g.adj[q]] == id) ++c;
+        if (leaf_id[g.adj[q]] == id) ++c;
       sub.ptr[t + 1] = sub.ptr[t] + c;
     }
     sub.adj.resize(sub.ptr[k]);
@@ -269,11 +287,27 @@ struct NDState {
       const int v = verts[t];
       int64_t o = sub.ptr[t];
       for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q)
-        if (inset[g.adj[q]] == id) sub.adj[o++] = local[g.adj[q]];
+        if (leaf_id[g.adj[q]] == id) sub.adj[o++] = local[g.adj[q]];
     }
     std::vector<int> lp;
     amd_order(sub, lp);
-    for (int t : lp) perm.push_back(verts[t]);
+    for (int t = 0; t < k; ++t) perm[task.off + t] = verts[lp[t]];
+  }
+
+  void run_leaves() {
+    const int nl = (int)leaves.size();
+    const int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      for (int i = next++; i < nl; i = next++) order_leaf(leaves[i], i);
+    };
+    if (nt <= 1 || nl <= 1) {
+      worker();
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < std::min(nt, nl); ++t) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
   }
 
   // BFS inside the stamped subset from root; returns vertices in BFS order and
@@ -446,6 +480,7 @@ void nd_order(const Graph& g, const NDParams& p, std::vector<int>& perm) {
   std::vector<int> all(g.n);
   std::iota(all.begin(), all.end(), 0);
   st.rec(std::move(all));
+  st.run_leaves();
   assert((int)perm.size() == g.n);
 }
 
