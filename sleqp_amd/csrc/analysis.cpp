@@ -24,9 +24,9 @@ namespace {
 
 // static-partition parallel loop over [0, n): fn(begin, end, thread_index)
 template <class F>
-void parallel_chunks(int n, F fn) {
+void parallel_chunks(int n, F fn, int grain = 2048) {
   const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-  const int nt = std::max(1, std::min({hw, 32, n / 2048 + 1}));
+  const int nt = std::max(1, std::min({hw, 32, n / grain + 1}));
   if (nt == 1) {
     fn(0, n, 0);
     return;
@@ -613,7 +613,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         }
         for (int t = 0; t < r; ++t) pos[rs[t]] = -1;
       }
-    });
+    }, 8);
     if (bad) {
       P.error = "internal: matrix entry outside front";
       return false;
