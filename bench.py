@@ -210,6 +210,16 @@ def main():
         achieved = bytes_per_launch / avg_s / 1e9
         factor_ms = sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor", "factorA", "factorB",
                                                           "factorC", "factorD") if k in prof)
+        # HBM traffic of the dominant kernel from the PMC counters (separate rocprofv3 --pmc passes of this
+        # same command, profiles/r1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            rec = pmc.get(kernel_names.get(dom, dom))
+            if rec and args.workload == "banded_n1e5_m5e4":
+                traffic = rec["fetch_bytes_per_launch_x2"] + rec["write_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "KKT factor+solve/sec (numeric refactor + 1 solve with residual-checked refinement, inputs resident in HBM)",
             "value": rep.aggregate_rate(args.steps, t_max),
@@ -231,7 +241,7 @@ def main():
                        "solves_per_factor": args.solves_per_factor,
                        "parallelism": f"replicas{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": kernel_names.get(dom, dom), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": prof[dom]["avg_launch_us"]},
             "kernels": prof,

@@ -1,0 +1,21 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+Units/corrections per MI355X_MICROARCH.md §HBM: the counters are in KiB; on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced streaming reads, so the read side is given both raw and x2 (upper bound)."""
+import csv, glob, sys, json
+def load(d, name):
+    path = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name: continue
+        k = r["Kernel_Name"].split("(")[0].replace("hipfact::", "")
+        a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+    return acc
+f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+print("%-26s %7s %14s %14s %14s" % ("kernel", "calls", "fetch KiB/call", "x2 (gfx950)", "write KiB/call"))
+for k in sorted(f, key=lambda k: -f[k][1]):
+    fc = f[k][1] / f[k][0]; wc = w.get(k, [1, 0.0])[1] / max(w.get(k, [1, 0])[0], 1)
+    print("%-26s %7d %14.1f %14.1f %14.1f" % (k[:26], f[k][0], fc, 2 * fc, wc))
+    out[k] = {"calls": f[k][0], "fetch_bytes_per_launch_raw": fc * 1024, "fetch_bytes_per_launch_x2": 2 * fc * 1024, "write_bytes_per_launch": wc * 1024}
+json.dump(out, open(sys.argv[3], "w"), indent=1)

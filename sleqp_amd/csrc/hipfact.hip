@@ -289,7 +289,7 @@ static int upload_plan(hipfact_handle* h) {
       work = std::max(work, (double)r * r * w);
     }
     const size_t wp = (size_t)((mw + 15) & ~15);
-    const size_t needB = wp * (wp + 1) + 16 * (wp + 1);
+    const size_t needB = wp * (wp + 1) + 16 * (wp + 1) + 32;
     const size_t needD = (size_t)128 * 64;  // two 64 x 64 operand strips
     li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
     li.lds_pivot = (wp + needB) * sizeof(double);
@@ -419,7 +419,7 @@ static int factor_enqueue(hipfact_handle* h) {
       LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), li.lds_asm, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
              h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
     if (li.split && h->debug_phases == 15) {
-      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(FB), li.lds_pivot, h->d_sn.as<SnDesc>(),
+      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(512), li.lds_pivot, h->d_sn.as<SnDesc>(),
              h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>());
       if (li.nC > 0)
         LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(FB), li.lds_panel, h->d_sn.as<SnDesc>(), it + li.itC,

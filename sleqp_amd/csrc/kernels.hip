@@ -187,134 +187,163 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
   }
 }
 
-// ---- phase B: pivot block in LDS -> inv(L11) (unit lower) in A, pivots in dd
+// 16 x 16 diagonal block kb: LDL^T and the inverse of its unit lower factor in
+// the registers of ONE wave.  lane (i = li, q = lk) owns A[i][4q..4q+3] and
+// X[i][4q..4q+3]; the cross-lane exchange goes through a 32-double LDS scratch
+// (LDS operations of one wave execute in order: a write followed by reads needs
+// no barrier).  Leaves inv(L_kk) in the block and the pivots in dd.
+__device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int lda = c.lda;
+  double* A = c.A;
+  double* colk = scratch;       // 16: A[.][k]
+  double* xrow = scratch + 16;  // 16: X[k][.]
+  double a[4], x[4];
+  double dmine = 1.0;  // pivot of column li (kept by the lanes with lk == 0)
+  int nzero = 0, nneg = 0;
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
+    x[cc] = (li == 4 * lk + cc) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int qk = k >> 2, kr = k & 3;
+    if (lk == qk) colk[li] = a[kr];
+    if (li == k) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) xrow[4 * lk + cc] = x[cc];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double ck_i = colk[li];                   // A[i][k]
+    double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
+                                                    // reciprocal chain overlaps the LDS round trip
+    double ckj[4], xk[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc
+      xk[cc] = xrow[4 * lk + cc];   // X[k][j]
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);  // exactly singular or non-finite
+    nzero += bad ? 1 : 0;
+    d = bad ? 1.0 : d;
+    nneg += (d < 0.0) ? 1 : 0;
+    dmine = (li == k) ? d : dmine;
+    const double l_ik = (li > k) ? ck_i * fast_rcp(d) : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int j = 4 * lk + cc;
+      a[cc] = (j > k) ? fma(-l_ik, ckj[cc], a[cc]) : a[cc];
+      x[cc] = fma(-l_ik, xk[cc], x[cc]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
+  if (lk == 0) c.dd[k0 + li] = dmine;
+  if (lane == 0 && (nzero | nneg)) {
+    if (nzero) atomicAdd(&info[INFO_ZERO_PIVOT], nzero);
+    if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);
+  }
+}
+
+// one 16 x 16 tile (I, J) of the trailing update A_IJ -= L_Ik Y_Jk^T (MFMA)
+__device__ __forceinline__ void dev_trailing_tile(const FrontCtx& c, int k0, int I, int J) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int lda = c.lda;
+  double* A = c.A;
+  const double* Yp = c.Yp;
+  d4_t acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = A[(16 * I + lk + 4 * q) + (16 * J + li) * lda];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const double av = -A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
+    const double bv = Yp[(16 * J + li) + (4 * s + lk) * lda];
+    acc = MFMA_F64(av, bv, acc);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) A[(16 * I + lk + 4 * q) + (16 * J + li) * lda] = acc[q];
+}
+
+// ---- phase B: pivot block in LDS -> inv(L11) (unit lower) in A, pivots in dd.
+// Blocked right-looking LDL^T (nb = 16) with look-ahead: in the trailing update of
+// step kb, wave 0 updates the next diagonal tile first and factors it at once,
+// while the other waves finish the remaining tiles.  Any number of waves >= 1.
 __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases = 15) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nw = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, wp = c.wp, nbk = c.nbk, lda = c.lda;
   double* A = c.A;
   double* dd = c.dd;
   double* Yp = c.Yp;
+  double* scratch = Yp + 16 * lda;  // 32 doubles for the diagonal-block micro-kernel
   const double* __restrict__ P = c.P;
   // eight columns per batch so that the panel loads are in flight together
-  for (int kk = wave; kk < wp; kk += 32)
+  for (int kk = wave; kk < wp; kk += 8 * nw)
     for (int i = lane; i < wp; i += 64) {
       double v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int k = kk + 4 * q;
+        const int k = kk + nw * q;
         v[q] = (i == k) ? 1.0 : 0.0;
         if (i < w && k < w) v[q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int k = kk + 4 * q;
+        const int k = kk + nw * q;
         if (k < wp) A[i + k * lda] = v[q];
       }
     }
   __syncthreads();
+  if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
+  __syncthreads();
 
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb << 4;
-    // S1: wave 0 factors the diagonal block and inverts its unit lower factor.
-    // lane (i = li, q = lk) owns A[i][4q..4q+3] and X[i][4q..4q+3].
-    if (wave == 0 && !(phases & 32)) {
-      // Cross-lane exchange through a 32-double LDS scratch (column k of A, row k
-      // of X): LDS operations of one wave execute in order, so a write followed by
-      // reads needs no barrier; far fewer instructions than ds_bpermute shuffles.
-      double* colk = Yp;        // 16: A[.][k]   (Yp is free during S1)
-      double* xrow = Yp + 16;   // 16: X[k][.]
-      double a[4], x[4];
-      double dmine = 1.0;  // pivot of column li (kept by the lanes with lk == 0)
-      int nzero = 0, nneg = 0;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
-        x[cc] = (li == 4 * lk + cc) ? 1.0 : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int qk = k >> 2, kr = k & 3;
-        if (lk == qk) colk[li] = a[kr];
-        if (li == k) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) xrow[4 * lk + cc] = x[cc];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double ck_i = colk[li];  // A[i][k]
-        double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
-                                                        // reciprocal chain overlaps the LDS round trip
-        double ckj[4], xk[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc
-          xk[cc] = xrow[4 * lk + cc];   // X[k][j]
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);  // exactly singular or non-finite
-        nzero += bad ? 1 : 0;
-        d = bad ? 1.0 : d;
-        nneg += (d < 0.0) ? 1 : 0;
-        dmine = (li == k) ? d : dmine;
-        const double l_ik = (li > k) ? ck_i * fast_rcp(d) : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int j = 4 * lk + cc;
-          a[cc] = (j > k) ? fma(-l_ik, ckj[cc], a[cc]) : a[cc];
-          x[cc] = fma(-l_ik, xk[cc], x[cc]);
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
-      if (lk == 0) dd[k0 + li] = dmine;
-      if (lane == 0 && (nzero | nneg)) {
-        if (nzero) atomicAdd(&info[INFO_ZERO_PIVOT], nzero);
-        if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);
-      }
-    }
-    __syncthreads();
     // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
     if (!(phases & 64))
-    for (int I = kb + 1 + wave; I < nbk; I += 4) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double av = A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
-        const double bv = A[(k0 + li) + (k0 + 4 * s + lk) * lda];
-        acc = MFMA_F64(av, bv, acc);
-      }
-      const double dinv = 1.0 / dd[k0 + li];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = 16 * I + lk + 4 * q;
-        Yp[row + li * lda] = acc[q];
-        A[row + (k0 + li) * lda] = acc[q] * dinv;
-      }
-    }
-    __syncthreads();
-    // S3: trailing update of the lower block triangle.
-    if (!(phases & 64)) {
-      const int T = nbk - kb - 1;
-      const int ntiles = T * (T + 1) / 2;
-      for (int t = wave; t < ntiles; t += 4) {
-        int J = 0, rem = t;
-        while (rem >= T - J) {
-          rem -= T - J;
-          ++J;
-        }
-        const int I = kb + 1 + J + rem;
-        J += kb + 1;
-        d4_t acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = A[(16 * I + lk + 4 * q) + (16 * J + li) * lda];
+      for (int I = kb + 1 + wave; I < nbk; I += nw) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const double av = -A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
-          const double bv = Yp[(16 * J + li) + (4 * s + lk) * lda];
+          const double av = A[(16 * I + li) + (k0 + 4 * s + lk) * lda];
+          const double bv = A[(k0 + li) + (k0 + 4 * s + lk) * lda];
           acc = MFMA_F64(av, bv, acc);
         }
+        const double dinv = 1.0 / dd[k0 + li];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) A[(16 * I + lk + 4 * q) + (16 * J + li) * lda] = acc[q];
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * I + lk + 4 * q;
+          Yp[row + li * lda] = acc[q];
+          A[row + (k0 + li) * lda] = acc[q] * dinv;
+        }
+      }
+    __syncthreads();
+    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)
+    if (kb + 1 < nbk) {
+      const int T = nbk - kb - 1;
+      const int ntiles = T * (T + 1) / 2;
+      if (wave == 0) {
+        if (!(phases & 64)) dev_trailing_tile(c, k0, kb + 1, kb + 1);
+        if (!(phases & 32)) dev_diag_block(c, scratch, k0 + 16, info);
+      }
+      if (!(phases & 64)) {
+        // remaining tiles over the other waves (over all waves when there is only one)
+        const int first = (nw > 1) ? 1 + (wave - 1) : 1;
+        const int step = (nw > 1) ? nw - 1 : 1;
+        if (nw == 1 || wave > 0)
+          for (int t = first; t < ntiles; t += step) {
+            int J = 0, rem = t;
+            while (rem >= T - J) {
+              rem -= T - J;
+              ++J;
+            }
+            dev_trailing_tile(c, k0, kb + 1 + J + rem, kb + 1 + J);
+          }
       }
     }
     __syncthreads();
@@ -383,7 +412,8 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
 // store inv(L11) (strict lower) and the pivots (diagonal) back to the panel
 __device__ __forceinline__ void dev_store_pivot_block(const FrontCtx& c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k < c.w; k += 4)
+  const int nw = blockDim.x >> 6;
+  for (int k = wave; k < c.w; k += nw)
     for (int i = k + lane; i < c.w; i += 64)
       c.P[i + (long long)k * c.r] = (i == k) ? c.dd[k] : c.A[i + k * c.lda];
 }
@@ -611,7 +641,7 @@ __global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restric
   dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts, reinterpret_cast<int*>(lds));
 }
 
-__global__ __launch_bounds__(FB) void k_front_pivot(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+__global__ __launch_bounds__(512) void k_front_pivot(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                     double* __restrict__ L, double* __restrict__ U,
                                                     int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
