@@ -323,7 +323,7 @@ static int upload_plan(hipfact_handle* h) {
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
         const int s = P.level_sn[q];
         const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
-        for (int b = 0; b < (u + 63) / 64; ++b) {
+        for (int b = 0; b < (u + 127) / 128; ++b) {  // 128 panel rows per workgroup (8 waves)
           items.push_back(s);
           items.push_back(b);
           ++li.nC;
@@ -422,7 +422,7 @@ static int factor_enqueue(hipfact_handle* h) {
       LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(512), li.lds_pivot, h->d_sn.as<SnDesc>(),
              h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>());
       if (li.nC > 0)
-        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(FB), li.lds_panel, h->d_sn.as<SnDesc>(), it + li.itC,
+        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(512), li.lds_panel, h->d_sn.as<SnDesc>(), it + li.itC,
                h->d_L.as<double>(), h->d_U.as<double>());
       if (li.nD > 0)
         LAUNCH(PC_FACTOR_D, k_front_schur, dim3(li.nD), dim3(FB), li.lds_schur, h->d_sn.as<SnDesc>(), it + li.itD,

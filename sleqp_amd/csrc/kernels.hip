@@ -421,20 +421,21 @@ __device__ __forceinline__ void dev_store_pivot_block(const FrontCtx& c) {
 // reload inv(L11) and the pivots from a finished panel (split kernels)
 __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool need_x) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < c.wp; k += FB) c.dd[k] = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
+  const int nw = blockDim.x >> 6;
+  for (int k = tid; k < c.wp; k += blockDim.x) c.dd[k] = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
   if (need_x)
-    for (int kk = wave; kk < c.wp; kk += 32)
+    for (int kk = wave; kk < c.wp; kk += 8 * nw)
       for (int i = lane; i < c.wp; i += 64) {
         double v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int k = kk + 4 * q;
+          const int k = kk + nw * q;
           v[q] = (i == k) ? 1.0 : 0.0;
           if (i < c.w && k < c.w && i > k) v[q] = c.P[i + (long long)k * c.r];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int k = kk + 4 * q;
+          const int k = kk + nw * q;
           if (k < c.wp) c.A[i + k * c.lda] = v[q];
         }
       }
@@ -453,7 +454,8 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
   const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
   const double* A = c.A;
   double* __restrict__ P = c.P;
-  for (int R0 = w + 64 * blk + 16 * wave; R0 < r; R0 += 64 * blk_stride) {
+  const int RB = 16 * (blockDim.x >> 6);  // panel rows per workgroup pass
+  for (int R0 = w + RB * blk + 16 * wave; R0 < r; R0 += RB * blk_stride) {
     const bool rok = (R0 + li) < r;
     const double* __restrict__ Prow = P + R0 + li;
     d4_t acc[8];
@@ -525,6 +527,7 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 // (64 rows x 64 pivots per chunk, k-major) staged in LDS: 64 KB per workgroup, so
 // that two workgroups share a CU and hide each other's staging latency.
 constexpr int KC = 64;
+template <bool DD_IN_LDS>
 __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -546,19 +549,21 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     const int kcn = min(KC, w - kc0);
     __syncthreads();  // previous chunk / tile has finished reading the strips
     for (int kk = tid >> 6; kk < kcn; kk += 32) {
-      double vi[8], vj[8];
+      double vi[8], vj[8], vd[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int k = kk + 4 * q;
         vi[q] = (iok && k < kcn) ? pi[(long long)(kc0 + k) * r] : 0.0;
         vj[q] = (jok && k < kcn) ? pj[(long long)(kc0 + k) * r] : 0.0;
+        // pivot d_k: LDS copy (fused kernel) or the panel diagonal (wave-uniform address)
+        vd[q] = (k < kcn) ? (DD_IN_LDS ? c.dd[kc0 + k] : c.P[(kc0 + k) + (long long)(kc0 + k) * r]) : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int k = kk + 4 * q;
         if (k < kcn) {
           SI[k * 64 + si] = vi[q];
-          SJ[k * 64 + si] = vj[q] * c.dd[kc0 + k];
+          SJ[k * 64 + si] = vj[q] * vd[q];
         }
       }
     }
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     double* SJ = c.A + 64 * KC;
     const int nt = (c.u + 63) >> 6;
     for (int I = 0; I < nt; ++I)
-      for (int J = 0; J <= I; ++J) dev_schur_tile(c, SI, SJ, I, J, S.child_begin == S.child_end);
+      for (int J = 0; J <= I; ++J) dev_schur_tile<true>(c, SI, SJ, I, J, S.child_begin == S.child_end);
   }
 }
 
@@ -651,13 +656,13 @@ __global__ __launch_bounds__(512) void k_front_pivot(const SnDesc* __restrict__ 
   dev_store_pivot_block(c);
 }
 
-__global__ __launch_bounds__(FB) void k_front_panel(const SnDesc* __restrict__ sn, const int* __restrict__ items,
+__global__ __launch_bounds__(512) void k_front_panel(const SnDesc* __restrict__ sn, const int* __restrict__ items,
                                                     double* __restrict__ L, double* __restrict__ U) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const SnDesc S = sn[items[2 * blockIdx.x]];
   const FrontCtx c = make_ctx(S, L, U, lds);
   dev_load_pivot_block(c, true);
-  dev_panel_solve<true>(c, items[2 * blockIdx.x + 1], 1 << 24);
+  dev_panel_solve<true>(c, items[2 * blockIdx.x + 1], 1 << 20);
 }
 
 // items: supernode, (I << 16) | J
@@ -666,9 +671,8 @@ __global__ __launch_bounds__(FB) void k_front_schur(const SnDesc* __restrict__ s
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const SnDesc S = sn[items[2 * blockIdx.x]];
   const FrontCtx c = make_ctx(S, L, U, lds);
-  dev_load_pivot_block(c, false);
   const int ij = items[2 * blockIdx.x + 1];
-  dev_schur_tile(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.child_begin == S.child_end);
+  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.child_begin == S.child_end);
 }
 
 // ---------------------------------------------------------------------------
