@@ -22,10 +22,11 @@ struct SnDesc {
   int parent;        // -1 for a root
   int child_begin;   // children in child_idx[child_begin, child_end)
   int child_end;
-  int pad0, pad1;
+  int pad0;  // elimination-tree level of the front
+  int pad1;
 };
 
 // info words written by the factorisation kernels
-enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_WORDS = 4 };
+enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_TIMEOUT = 2, INFO_WORDS = 4 };
 
 }  // namespace hipfact

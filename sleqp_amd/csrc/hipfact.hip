@@ -108,6 +108,7 @@ struct hipfact_handle {
   PlanParams prm;
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
+  bool idx32 = false;  // product-list pointers and panel targets fit 32 bits
   int refine_steps = 1;
   bool refine_adaptive = true;   // run the correction pass only when the residual asks for it
   double refine_tol = 5e-13;     // on ||b - K z||_inf / ||b||_inf
@@ -128,10 +129,13 @@ struct hipfact_handle {
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
+  // top of the tree solved in one launch per direction (levels >= top_level)
+  int top_level = 1 << 30, top_count = 0, top_max_fronts = 192;
+  size_t top_lds_fwd = 0, top_lds_bwd = 0;
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items;
+  DevBuf d_items, d_top_sn, d_flags;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -230,7 +234,8 @@ static int upload_plan(hipfact_handle* h) {
     d.parent = P.sn_parent[s];
     d.child_begin = P.child_ptr[s];
     d.child_end = P.child_ptr[s + 1];
-    d.pad0 = d.pad1 = 0;
+    d.pad0 = P.sn_level[s];
+    d.pad1 = 0;
   }
   int rc;
   if ((rc = upload(h, h->d_sn, sn))) return rc;
@@ -238,12 +243,21 @@ static int upload_plan(hipfact_handle* h) {
   if ((rc = upload(h, h->d_rows, P.sn_rows))) return rc;
   if ((rc = upload(h, h->d_rel, P.rel))) return rc;
   if ((rc = upload(h, h->d_child, P.child_idx))) return rc;
-  if ((rc = upload(h, h->d_Mtarget, P.Mtarget))) return rc;
+  h->idx32 = P.saddle && P.L_size < (1LL << 32) && P.nprod < (1LL << 32);
+  if (h->idx32) {
+    std::vector<unsigned int> t32(P.Mtarget.begin(), P.Mtarget.end());
+    if ((rc = upload(h, h->d_Mtarget, t32))) return rc;
+  } else if ((rc = upload(h, h->d_Mtarget, P.Mtarget)))
+    return rc;
   if ((rc = upload(h, h->d_perm, P.perm))) return rc;
   if ((rc = upload(h, h->d_Kp, P.Kp))) return rc;
   if ((rc = upload(h, h->d_Ki, P.Ki))) return rc;
   if (P.saddle) {
-    if ((rc = upload(h, h->d_prod_ptr, P.prod_ptr))) return rc;
+    if (h->idx32) {
+      std::vector<unsigned int> p32(P.prod_ptr.begin(), P.prod_ptr.end());
+      if ((rc = upload(h, h->d_prod_ptr, p32))) return rc;
+    } else if ((rc = upload(h, h->d_prod_ptr, P.prod_ptr)))
+      return rc;
     if ((rc = upload(h, h->d_prod_a, P.prod_a))) return rc;
     if ((rc = upload(h, h->d_prod_b, P.prod_b))) return rc;
     if ((rc = upload(h, h->d_Ar_ptr, P.Ar_ptr))) return rc;
@@ -354,12 +368,34 @@ static int upload_plan(hipfact_handle* h) {
       (h->levels[l].split ? h->rows_split : h->rows_fused) += r;
     }
   if ((rc = upload(h, h->d_items, items))) return rc;
+  {
+    // levels merged into the single-launch top-of-tree solve: as many of the last levels as fit
+    // the co-residency cap, and only if that saves at least two launches
+    int lvl = P.nlevels, total = 0;
+    while (lvl > 0 && total + h->levels[lvl - 1].count <= h->top_max_fronts) total += h->levels[--lvl].count;
+    h->top_level = 1 << 30;
+    h->top_count = 0;
+    if (P.nlevels - lvl >= 3 && h->top_max_fronts > 0) {
+      h->top_level = lvl;
+      h->top_count = total;
+      std::vector<int> top;
+      h->top_lds_fwd = h->top_lds_bwd = 0;
+      for (int l = lvl; l < P.nlevels; ++l) {
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) top.push_back(P.level_sn[q]);
+        h->top_lds_fwd = std::max(h->top_lds_fwd, h->levels[l].lds_fwd);
+        h->top_lds_bwd = std::max(h->top_lds_bwd, h->levels[l].lds_bwd);
+      }
+      if ((rc = upload(h, h->d_top_sn, top))) return rc;
+    }
+    HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)ns * sizeof(int), 16)));
+  }
   if (max_lds > 160 * 1024) {
     h->error = "front too large for LDS-resident solve vectors";
     return HIPFACT_EINTERNAL;
   }
   for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot), reinterpret_cast<const void*>(k_front_panel),
-                         reinterpret_cast<const void*>(k_front_schur)})
+                         reinterpret_cast<const void*>(k_front_schur), reinterpret_cast<const void*>(k_fwd_top),
+                         reinterpret_cast<const void*>(k_bwd_top)})
     HCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_factor_level),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -399,9 +435,14 @@ static int factor_enqueue(hipfact_handle* h) {
   const long long nM = (long long)P.Mi.size();
   if (nM > 0) {
     if (P.saddle) {
-      LAUNCH(PC_MVALS, k_mvals_prod, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
-                         h->d_prod_ptr.as<long long>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
-                         h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+      if (h->idx32)
+        LAUNCH(PC_MVALS, k_mvals_prod<unsigned int>, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
+               h->d_prod_ptr.as<unsigned int>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
+               h->d_Mtarget.as<unsigned int>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+      else
+        LAUNCH(PC_MVALS, k_mvals_prod<long long>, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
+               h->d_prod_ptr.as<long long>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
+               h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
     } else {
       LAUNCH(PC_MVALS, k_mvals_src, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM, h->d_src.as<int>(),
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
@@ -465,17 +506,27 @@ static int check_info(hipfact_handle* h) {
 // M y = t on the device (y in: t in pivot order, out: solution)
 static void solve_m_async(hipfact_handle* h) {
   const Plan& P = h->plan;
-  for (int l = 0; l < P.nlevels; ++l) {
+  const int ltop = std::min(h->top_level, P.nlevels);
+  for (int l = 0; l < ltop; ++l) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(SB), li.lds_fwd, h->d_sn.as<SnDesc>(),
-                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(),
-                       h->d_child.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>());
+           h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
+           h->d_y.as<double>(), h->d_uvec.as<double>());
   }
-  for (int l = P.nlevels - 1; l >= 0; --l) {
+  if (ltop < P.nlevels) {
+    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
+    LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
+           h->d_top_sn.as<int>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
+           h->d_y.as<double>(), h->d_uvec.as<double>(), h->d_flags.as<int>(), h->d_info.as<int>());
+    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
+    LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
+           h->d_top_sn.as<int>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
+           h->d_flags.as<int>(), h->d_info.as<int>());
+  }
+  for (int l = ltop - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_BWD, k_bwd_level, dim3(li.count), dim3(SB), li.lds_bwd, h->d_sn.as<SnDesc>(),
-                       h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(),
-                       h->d_y.as<double>());
+           h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>());
   }
 }
 
@@ -712,6 +763,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   }
   if (const char* s = getenv("HIPFACT_REFINE")) h->refine_steps = atoi(s);
   if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
+  if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
   *out = h;
   return HIPFACT_OK;
@@ -844,8 +896,13 @@ int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
   HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
   HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
+  HCHECK(h, hipMemcpyAsync(h->h_info.p, h->d_info.p, INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   memcpy(out, h->h_stage.p, cnt * sizeof(double));
+  if (h->h_info.as<int>()[INFO_TIMEOUT] != 0) {
+    h->error = "hipfact_solution: dependency wait timed out inside the top-of-tree solve kernel";
+    return HIPFACT_EINTERNAL;
+  }
   return HIPFACT_OK;
 }
 
@@ -1124,6 +1181,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     if (!h->use_graph) drop_graphs(h);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "top_max_fronts")) {  // 0 disables the single-launch top-of-tree solve
+    h->top_max_fronts = (int)value;
+    drop_graphs(h);
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "split_max_fronts")) {
     h->split_max_fronts = (int)value;
     drop_graphs(h);
@@ -1196,6 +1260,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
+  INFO("top_level", h->top_level) INFO("top_count", h->top_count) INFO("solve_timeouts", h->h_info.p ? h->h_info.as<int>()[INFO_TIMEOUT] : 0)
   INFO("use_graph", h->use_graph) INFO("num_graphs", h->graphs.size()) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
   INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
   INFO("rows_total", P.sn_rows.size()) INFO("ent_fused", h->ent_fused) INFO("ent_split", h->ent_split)

@@ -33,17 +33,22 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Saddle mode: elimination of the n leaf columns x of K = [I A^T; A 0].
 // M(i,k) = S(i,k) = sum_j A(i,j) A(k,j), summed in the fixed order of the
 // product list (deterministic), written straight into its front panel.
-__global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const long long* __restrict__ prod_ptr,
+template <class IDX>
+__global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __restrict__ prod_ptr,
                                                    const int* __restrict__ prod_a, const int* __restrict__ prod_b,
-                                                   const long long* __restrict__ target,
-                                                   const double* __restrict__ Kval, double* __restrict__ L) {
+                                                   const IDX* __restrict__ target, const double* __restrict__ Kval,
+                                                   double* __restrict__ L) {
   for (long long e = blockIdx.x * (long long)FB + threadIdx.x; e < nM; e += (long long)gridDim.x * FB) {
     double s = 0.0;
-    const long long p1 = prod_ptr[e + 1];
-    for (long long p = prod_ptr[e]; p < p1; ++p) s += Kval[prod_a[p]] * Kval[prod_b[p]];
-    L[target[e]] = s;
+    const long long p1 = (long long)prod_ptr[e + 1];
+    for (long long p = (long long)prod_ptr[e]; p < p1; ++p) s += Kval[prod_a[p]] * Kval[prod_b[p]];
+    L[(long long)target[e]] = s;
   }
 }
+template __global__ void k_mvals_prod<long long>(long long, const long long*, const int*, const int*,
+                                                 const long long*, const double*, double*);
+template __global__ void k_mvals_prod<unsigned int>(long long, const unsigned int*, const int*, const int*,
+                                                    const unsigned int*, const double*, double*);
 
 // Generic mode: M(e) = K(src[e]).
 __global__ __launch_bounds__(FB) void k_mvals_src(long long nM, const int* __restrict__ src,
@@ -683,13 +688,12 @@ __global__ __launch_bounds__(FB) void k_front_schur(const SnDesc* __restrict__ s
 // ---------------------------------------------------------------------------
 constexpr int SB = 1024;  // threads per block of the solve kernels (16 waves hide the panel-read latency)
 
-__global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
-                                                  const double* __restrict__ L, const int* __restrict__ rel,
-                                                  const int* __restrict__ child_idx, double* __restrict__ y,
-                                                  double* __restrict__ uvec) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+// forward step of one front (all threads of the block; lds: r + 9 w + 1024 doubles)
+__device__ __forceinline__ void dev_fwd_front(const SnDesc& S, const SnDesc* __restrict__ sn,
+                                              const double* __restrict__ L, const int* __restrict__ rel,
+                                              const int* __restrict__ child_idx, double* __restrict__ y,
+                                              double* __restrict__ uvec, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SnDesc S = sn[level_sn[blockIdx.x]];
   const int w = S.w, r = S.r, u = r - w;
   const double* __restrict__ P = L + S.Loff;
   double* f = lds;              // r
@@ -785,12 +789,20 @@ __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn,
   }
 }
 
-__global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
-                                                  const double* __restrict__ L, const int* __restrict__ rows,
-                                                  double* __restrict__ y) {
+
+__global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+                                                  const double* __restrict__ L, const int* __restrict__ rel,
+                                                  const int* __restrict__ child_idx, double* __restrict__ y,
+                                                  double* __restrict__ uvec) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SnDesc S = sn[level_sn[blockIdx.x]];
+  dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
+}
+
+// backward step of one front (lds: u + w doubles)
+__device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __restrict__ L,
+                                              const int* __restrict__ rows, double* __restrict__ y, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = S.w, r = S.r, u = r - w;
   const double* __restrict__ P = L + S.Loff;
   const int* __restrict__ rw = rows + S.rowoff + w;
@@ -891,6 +903,83 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
       }
     }
   }
+}
+
+
+__global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
+                                                  const double* __restrict__ L, const int* __restrict__ rows,
+                                                  double* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SnDesc S = sn[level_sn[blockIdx.x]];
+  dev_bwd_front(S, L, rows, y, lds);
+}
+
+// ---------------------------------------------------------------------------
+// Top of the elimination tree in ONE launch per direction.  The last levels hold
+// a handful of fronts each, so a kernel per level is pure launch + dependent
+// latency.  Here every front of those levels gets its own workgroup (all of
+// them co-resident: the host caps their number far below the resident capacity),
+// and the tree dependencies are enforced with one done-flag per front:
+//   producer: all waves drain their stores, block barrier, one lane issues an
+//             agent-scope release and then a relaxed agent-scope flag store;
+//   consumer: one lane polls the flag (relaxed, agent scope, bounded spin), then
+//             an agent-scope acquire, block barrier, plain loads.
+// Flags are zeroed by a memset node before every launch.  A spin that runs out
+// sets INFO_TIMEOUT instead of hanging the GPU.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(&flags[who], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) {
+        atomicAdd(&info[INFO_TIMEOUT], 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void top_publish(int* __restrict__ flags, int who) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&flags[who], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// top_sn: fronts of the levels >= top_level; S.pad0 holds the level of a front
+__global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, const int* __restrict__ top_sn,
+                                                int top_level, const double* __restrict__ L,
+                                                const int* __restrict__ rel, const int* __restrict__ child_idx,
+                                                double* __restrict__ y, double* __restrict__ uvec,
+                                                int* __restrict__ flags, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = top_sn[blockIdx.x];
+  const SnDesc S = sn[s];
+  for (int ci = S.child_begin; ci < S.child_end; ++ci) {
+    const int c = child_idx[ci];
+    if (sn[c].pad0 >= top_level) top_wait(flags, c, info);
+  }
+  dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
+  top_publish(flags, s);
+}
+
+__global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, const int* __restrict__ top_sn,
+                                                const double* __restrict__ L, const int* __restrict__ rows,
+                                                double* __restrict__ y, int* __restrict__ flags,
+                                                int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = top_sn[blockIdx.x];
+  const SnDesc S = sn[s];
+  if (S.parent >= 0) top_wait(flags, S.parent, info);  // the parent is done only after all its ancestors
+  dev_bwd_front(S, L, rows, y, lds);
+  top_publish(flags, s);
 }
 
 // ---------------------------------------------------------------------------
