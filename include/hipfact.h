@@ -151,6 +151,29 @@ int hipfact_spmat_mult_vec_sym(hipfact_spmat* M, const double* x, double* y);
 /* Device-resident forms: trans = 0 (M x), 1 (M^T x), 2 (symmetric-from-lower). */
 int hipfact_spmat_mult_device(hipfact_spmat* M, int trans, const double* d_x, double* d_y);
 
+/* ---- device-resident projected CG (the caller of the path) -------------- */
+
+/* Replaces the loop of steihaug_solver_solve (tr/steihaug_solver.c:218-496, the
+ * SleqpTRCallbacks.solve slot of tr/tr_types.h:9-29, selected with TR_SOLVER=CG or
+ * AUTO + SLEQP_FUNC_HESS_PSD, newton.c:97-109) for problems whose Hessian of the
+ * Lagrangian is available as an explicit matrix: every CG vector (z, r, g, d,
+ * B d) stays in HBM, the null-space projection is the factorised KKT solve of
+ * this handle (aug_jac_project_nullspace, standard_aug_jac.c:396-435), the
+ * Hessian product is the symmetric SpMV of `hess` (lower-triangular CSC, the
+ * prod_from_hess_matrix precedent, bindings/mex/mex_hess.c:85-139).  Per
+ * iteration only three scalars cross PCIe instead of two n-vectors plus the
+ * sparse<->dense marshal of the reference.
+ *   gradient     host, n doubles           newton_step  host out, n doubles
+ *   rel_tol      stat_eps * 1e-2 in the reference (steihaug_solver.c:21,241)
+ *   max_iter     SLEQP_SETTINGS_INT_MAX_NEWTON_ITERATIONS (-1: none)
+ *   tr_dual      out, multiplier of the trust-region constraint (steihaug_tr_dual,
+ *                :187-216; -1 = SLEQP_NONE when the step is interior)
+ *   iterations   out, number of CG iterations performed
+ * Boundary hits use sleqp_tr_compute_bdry_sol (tr/tr_util.c:8-58).  Like the
+ * reference, the step is zero when max_iter is exhausted before convergence. */
+int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double* gradient, double trust_radius,
+                           double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations);
+
 /* ---- options / introspection ------------------------------------------- */
 
 /* Options: "refine_steps" (iterative-refinement steps per solve, default 1),

@@ -29,7 +29,7 @@ SYMBOLS = [
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_stream",
     "hipfact_assemble_kkt", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
     "hipfact_spmat_mult_vec", "hipfact_spmat_mult_vec_trans", "hipfact_spmat_mult_vec_sym",
-    "hipfact_spmat_mult_device", "hipfact_set_option", "hipfact_get_info", "hipfact_plan_create",
+    "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_set_option", "hipfact_get_info", "hipfact_plan_create",
     "hipfact_plan_free", "hipfact_plan_error", "hipfact_plan_array", "hipfact_plan_scalar",
 ]
 
@@ -75,6 +75,7 @@ def load() -> C.CDLL:
     lib.hipfact_spmat_mult_vec_trans.argtypes = [vp, vp, vp]
     lib.hipfact_spmat_mult_vec_sym.argtypes = [vp, vp, vp]
     lib.hipfact_spmat_mult_device.argtypes = [vp, ci, vp, vp]
+    lib.hipfact_steihaug_solve.argtypes = [vp, vp, vp, cd, cd, ci, vp, C.POINTER(cd), C.POINTER(ci)]
     lib.hipfact_set_option.argtypes = [vp, C.c_char_p, cd]
     lib.hipfact_get_info.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
     lib.hipfact_plan_create.argtypes = [ci, vp, vp, vp, C.POINTER(vp)]

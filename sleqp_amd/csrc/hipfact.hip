@@ -143,6 +143,9 @@ struct hipfact_handle {
   PinBuf h_stage, h_info;
   // assembly
   DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
+  // projected CG
+  DevBuf d_cg_b, d_cg_z, d_cg_vec, d_cg_dots;
+  PinBuf h_cg_dots;
 };
 
 struct hipfact_spmat {
@@ -1160,6 +1163,134 @@ static int spmat_host_mult(hipfact_spmat* M, int trans, const double* x, double*
 int hipfact_spmat_mult_vec(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 0, x, y); }
 int hipfact_spmat_mult_vec_trans(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 1, x, y); }
 int hipfact_spmat_mult_vec_sym(hipfact_spmat* M, const double* x, double* y) { return spmat_host_mult(M, 2, x, y); }
+
+// ---------------------------------------------------------------------------
+// three dot products in one launch + one small copy back; fixed summation order
+static int cg_dots(hipfact_handle* h, int n, const double* x0, const double* y0, const double* x1, const double* y1,
+                   const double* x2, const double* y2, double out[3]) {
+  hipLaunchKernelGGL(k_dots3, dim3(DOT_BLOCKS), dim3(FB), 0, h->stream, n, x0, y0, x1, y1, x2, y2,
+                     h->d_cg_dots.as<double>());
+  HCHECK(h, hipMemcpyAsync(h->h_cg_dots.p, h->d_cg_dots.p, 3 * DOT_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  const double* p = h->h_cg_dots.as<double>();
+  out[0] = out[1] = out[2] = 0.0;
+  for (int b = 0; b < DOT_BLOCKS; ++b)
+    for (int t = 0; t < 3; ++t) out[t] += p[3 * b + t];
+  return HIPFACT_OK;
+}
+
+int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double* gradient, double trust_radius,
+                           double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if ((rc = require_factor(h, "hipfact_steihaug_solve"))) return rc;
+  const Plan& P = h->plan;
+  const int n = P.saddle ? P.n : 0;
+  if (!P.saddle || !hess || hess->h != h || hess->rows != n || hess->cols != n || !gradient || !newton_step ||
+      !(trust_radius > 0.0)) {
+    h->error = "hipfact_steihaug_solve: needs a factorised saddle matrix and an n x n Hessian on the same handle";
+    return HIPFACT_EINVAL;
+  }
+  const int N = P.N;
+  hipStream_t st = h->stream;
+  const size_t nb = (size_t)n * sizeof(double);
+  HCHECK(h, h->d_cg_b.ensure((size_t)N * sizeof(double)));
+  HCHECK(h, h->d_cg_z.ensure((size_t)N * sizeof(double)));
+  HCHECK(h, h->d_cg_vec.ensure(4 * nb + 64));
+  HCHECK(h, h->d_cg_dots.ensure(3 * DOT_BLOCKS * sizeof(double)));
+  HCHECK(h, h->h_cg_dots.ensure(3 * DOT_BLOCKS * sizeof(double)));
+  HCHECK(h, h->h_stage.ensure(nb));
+  // r lives in the head of the KKT right-hand side [r; 0]; g is the head of the KKT solution
+  double* r = h->d_cg_b.as<double>();
+  const double* g = h->d_cg_z.as<double>();
+  double* z = h->d_cg_vec.as<double>();
+  double* d = z + n;
+  double* Bd = d + n;
+  double* grad = Bd + n;
+  HCHECK(h, hipStreamSynchronize(st));
+  memcpy(h->h_stage.p, gradient, nb);
+  HCHECK(h, hipMemsetAsync(h->d_cg_b.p, 0, (size_t)N * sizeof(double), st));
+  HCHECK(h, hipMemcpyAsync(r, h->h_stage.p, nb, hipMemcpyHostToDevice, st));
+  HCHECK(h, hipMemcpyAsync(grad, r, nb, hipMemcpyDeviceToDevice, st));
+  HCHECK(h, hipMemsetAsync(z, 0, nb, st));
+  const int vb = nblocks(n);
+  const double rel_tol_sq = rel_tol * rel_tol;
+  const double rad_sq = trust_radius * trust_radius;
+  double dots[3];
+  if (tr_dual) *tr_dual = -1.0;  // SLEQP_NONE
+  int it = 0;
+  bool boundary = false;
+
+  // g0 = P[r0], d0 = -g0
+  if ((rc = solve_async(h, h->d_cg_b.as<double>(), h->d_cg_z.as<double>()))) return rc;
+  HCHECK(h, hipMemsetAsync(d, 0, nb, st));
+  hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -1.0, g, 0.0, d);
+  if ((rc = cg_dots(h, n, d, d, r, g, nullptr, nullptr, dots))) return rc;
+  double d_nrm_sq = dots[0], r_dot_g = dots[1];
+  double z_nrm_sq = 0.0;
+  if (!(d_nrm_sq < rel_tol_sq)) {
+    for (it = 0;; ++it) {
+      if (max_iter != -1 && it >= max_iter) {
+        // the reference leaves newton_step cleared when the iteration cap is hit before any of
+        // its exit tests (steihaug_solver.c:254,282-285): mirrored, the step is zero
+        HCHECK(h, hipMemsetAsync(z, 0, nb, st));
+        break;
+      }
+      if (fabs(r_dot_g) < rel_tol_sq) break;  // interior solution p = z
+      // B d, d^T B d, z^T d
+      if ((rc = hipfact_spmat_mult_device(hess, 2, d, Bd))) return rc;
+      if ((rc = cg_dots(h, n, d, Bd, z, d, d, d, dots))) return rc;
+      const double dBd = dots[0], z_dot_d = dots[1];
+      d_nrm_sq = dots[2];
+      if (dBd <= 0.0) {
+        // negative curvature: go to the boundary along d, pick the better of the two intersections
+        double e2[3];
+        if ((rc = cg_dots(h, n, grad, d, z, Bd, nullptr, nullptr, e2))) return rc;
+        const double gd = e2[0], zBd = e2[1];
+        const double inner = z_dot_d * z_dot_d - d_nrm_sq * (z_nrm_sq - rad_sq);
+        const double tau_min = 1. / d_nrm_sq * (-z_dot_d - sqrt(inner));
+        const double tau_max = 1. / d_nrm_sq * (-z_dot_d + sqrt(inner));
+        const double obj_min = tau_min * ((gd + zBd) + 0.5 * tau_min * dBd);
+        const double obj_max = tau_max * ((gd + zBd) + 0.5 * tau_max * dBd);
+        const double tau = (obj_min < obj_max) ? tau_min : tau_max;
+        hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, tau, d, 1.0, z);
+        break;
+      }
+      const double alpha = r_dot_g / dBd;
+      const double z_next_nrm_sq = z_nrm_sq + 2.0 * alpha * z_dot_d + alpha * alpha * d_nrm_sq;
+      if (z_next_nrm_sq >= rad_sq) {
+        // sleqp_tr_compute_bdry_sol (tr/tr_util.c:8-58)
+        const double inner = z_dot_d * z_dot_d - d_nrm_sq * (z_nrm_sq - rad_sq);
+        const double factor = 1. / d_nrm_sq * (-z_dot_d + sqrt(inner));
+        hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, factor, d, 1.0, z);
+        boundary = true;
+        break;
+      }
+      hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, alpha, d, 1.0, z);   // z += alpha d
+      hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, alpha, Bd, 1.0, r);  // r += alpha B d
+      z_nrm_sq = z_next_nrm_sq;
+      if ((rc = solve_async(h, h->d_cg_b.as<double>(), h->d_cg_z.as<double>()))) return rc;  // g = P[r]
+      if ((rc = cg_dots(h, n, r, g, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+      const double beta = dots[0] / r_dot_g;
+      r_dot_g = dots[0];
+      hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -1.0, g, beta, d);  // d = -g + beta d
+    }
+  }
+  if (boundary && tr_dual) {
+    // steihaug_tr_dual (steihaug_solver.c:187-216)
+    if ((rc = hipfact_spmat_mult_device(hess, 2, z, Bd))) return rc;
+    if ((rc = cg_dots(h, n, z, Bd, z, grad, nullptr, nullptr, dots))) return rc;
+    const double comb = dots[0] + dots[1];
+    *tr_dual = comb < 0.0 ? (-comb) / rad_sq : 0.0;
+  }
+  HCHECK(h, hipGetLastError());
+  HCHECK(h, hipMemcpyAsync(h->h_stage.p, z, nb, hipMemcpyDeviceToHost, st));
+  HCHECK(h, hipStreamSynchronize(st));
+  memcpy(newton_step, h->h_stage.p, nb);
+  if (iterations) *iterations = it;
+  return HIPFACT_OK;
+}
 
 // ---------------------------------------------------------------------------
 int hipfact_set_option(hipfact_handle* h, const char* name, double value) {

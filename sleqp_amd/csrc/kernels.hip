@@ -1145,6 +1145,47 @@ __global__ __launch_bounds__(FB) void k_axpy(long long n, double a, const double
     y[i] += a * x[i];
 }
 
+// ---------------------------------------------------------------------------
+// Vector kernels of the device-resident projected CG (tr/steihaug_solver.c).
+// Dot products leave one partial per block (fixed grid, fixed order: the host
+// sums them in index order => deterministic).
+// ---------------------------------------------------------------------------
+constexpr int DOT_BLOCKS = 128;
+
+// out[3 * blockIdx + t] = partial of <x_t, y_t>, t = 0, 1, 2 (null pointers skip a pair)
+__global__ __launch_bounds__(FB) void k_dots3(int n, const double* __restrict__ x0, const double* __restrict__ y0,
+                                              const double* __restrict__ x1, const double* __restrict__ y1,
+                                              const double* __restrict__ x2, const double* __restrict__ y2,
+                                              double* __restrict__ out) {
+  __shared__ double sh[3][FB / 64];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) {
+    if (x0) s0 += x0[i] * y0[i];
+    if (x1) s1 += x1[i] * y1[i];
+    if (x2) s2 += x2[i] * y2[i];
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s0;
+    sh[1][threadIdx.x >> 6] = s1;
+    sh[2][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int q = 0; q < FB / 64; ++q) s += sh[threadIdx.x][q];
+    out[3 * blockIdx.x + threadIdx.x] = s;
+  }
+}
+
+// y = a x + b y
+__global__ __launch_bounds__(FB) void k_axpby(int n, double a, const double* __restrict__ x, double b,
+                                              double* __restrict__ y) {
+  for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) y[i] = a * x[i] + b * y[i];
+}
+
 __global__ __launch_bounds__(FB) void k_scatter(long long n, const int* __restrict__ idx,
                                                 const double* __restrict__ in, double* __restrict__ out) {
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)

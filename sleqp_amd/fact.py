@@ -128,6 +128,15 @@ class HipFact:
         nnz = k_nnz.value
         return SleqpMat(N, N, kp, ki[:nnz].copy(), kx[:nnz].copy())
 
+    def steihaug(self, hess: "SpMat", gradient, trust_radius: float, stat_tol: float = 1e-6, max_iter: int = 100):
+        """Device-resident projected CG (tr/steihaug_solver.c:218-496): returns (step, tr_dual, iterations)."""
+        g = np.ascontiguousarray(gradient, dtype=np.float64)
+        step = np.empty_like(g)
+        dual, its = C.c_double(), C.c_int()
+        self._check(self._lib.hipfact_steihaug_solve(self._h, hess._m, _ptr(g), float(trust_radius), stat_tol * 1e-2,
+                                                     int(max_iter), _ptr(step), C.byref(dual), C.byref(its)))
+        return step, dual.value, its.value
+
     def free(self):
         if self._h:
             self._lib.hipfact_free(C.byref(self._h))

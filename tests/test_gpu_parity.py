@@ -395,3 +395,66 @@ def test_adaptive_refinement_and_graphs(fact):
     fact.set_matrix(SleqpMat(N2, N2, c2, r2, d2))
     fact.solve(b)
     assert scaled_residual(K2, fact.solution_raw(0, N2), b) <= RESID_TOL
+
+
+def test_device_steihaug_known_answers(fact):
+    """Reference known answers through the device-resident projected CG
+    (constrained_newton_test.c:204-275, unconstrained_newton_test.c:67-205)."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    H = SpMat(fact, SleqpMat(2, 2, [0, 1, 2], [0, 1], [2.0, 2.0]))  # hess_prod = 2 * direction
+    grad = np.array([2.0, 4.0])
+    aug = StandardAugJac(2, fact)
+    aug.set_iterate(SleqpMat(1, 2, [0, 0, 1], [0], [1.0]), [-1, -1], [0])  # c = x1 active
+    step, dual, its = fact.steihaug(H, grad, 10.0)
+    assert np.allclose(step, [-1.0, 0.0], atol=1e-8) and dual == -1.0
+    aug.set_iterate(SleqpMat(0, 2, [0, 0, 0], [], []), [-1, -1], [])  # empty working set
+    step, dual, its = fact.steihaug(H, grad, 10.0)
+    assert np.allclose(step, [-1.0, -2.0], atol=1e-8)
+    step, dual, its = fact.steihaug(H, grad, 1.0)  # trust region active
+    assert np.allclose(step, [-0.44721359549995793, -0.89442719099991586], atol=1e-8)
+    assert dual >= 0.0
+
+
+@pytest.mark.parametrize("radius", [0.3, 5.0, 1e3])
+def test_device_steihaug_vs_oracle(fact, radius):
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 400, 150
+    J, vi, ci, W = _problem(n, m, "u", 0.05, 11)
+    B = sp.random(n, n, density=0.02, random_state=3)
+    Hm = (B @ B.T + 0.5 * sp.eye(n)).tocsc()
+    HL = sp.tril(Hm, format="csc")
+    HL.sort_indices()
+    g = np.random.default_rng(5).standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    want, its_ref = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    H = SpMat(fact, SleqpMat.from_scipy(HL))
+    step, dual, its = fact.steihaug(H, g, radius)
+    assert its == its_ref
+    assert rel_err(step, want) <= 1e-8
+    # the step lies in the null space of the working-set rows and inside the trust region
+    A_W = sp.vstack([sp.eye(n, format="csr")[np.nonzero(vi >= 0)[0]], J.tocsr()])
+    assert np.abs(A_W @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(A_W).sum(axis=1).max()
+    assert np.linalg.norm(step) <= radius * (1 + 1e-10)
+
+
+def test_device_steihaug_negative_curvature(fact):
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 60, 20
+    J, vi, ci, W = _problem(n, m, "u", 0.0, 4)
+    Hd = sp.diags(np.linspace(-1.0, 2.0, n)).tocsc()  # indefinite Hessian
+    g = np.random.default_rng(1).standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    want, its_ref = oracle.OracleFact(N, kc, kr, kd).steihaug(n, Hd.indptr, Hd.indices, Hd.data, g, trust_radius=2.0)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    step, dual, its = fact.steihaug(SpMat(fact, SleqpMat.from_scipy(Hd)), g, 2.0)
+    assert rel_err(step, want) <= 1e-8
+    assert abs(np.linalg.norm(step) - 2.0) <= 1e-9  # ends on the boundary
