@@ -458,3 +458,43 @@ def test_device_steihaug_negative_curvature(fact):
     step, dual, its = fact.steihaug(SpMat(fact, SleqpMat.from_scipy(Hd)), g, 2.0)
     assert rel_err(step, want) <= 1e-8
     assert abs(np.linalg.norm(step) - 2.0) <= 1e-9  # ends on the boundary
+
+
+def test_concurrent_instances_like_thread_test():
+    """thread_test.c:13-110: 8 threads, each builds and uses its own solver state; here 8 backend
+    instances on one GPU (own stream / buffers / symbolic cache each), checked against the oracle."""
+    import threading
+
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    results = [None] * 8
+
+    def worker(t):
+        try:
+            n, m = 300 + 40 * t, 120 + 10 * t
+            J, vi, ci, W = _problem(n, m, "b" if t % 2 else "u", 0.05, 20 + t)
+            N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+            b = np.random.default_rng(t).standard_normal(N)
+            f = HipFact(device=0)
+            errs = []
+            for rep in range(3):
+                f.set_matrix(SleqpMat(N, N, kc, kr, kd))
+                f.solve(b)
+                z = f.solution_raw(0, N)
+                ref = oracle.OracleFact(N, kc, kr, kd)
+                ref.solve_dense(b)
+                errs.append(rel_err(z, ref.raw_solution()))
+            f.free()
+            results[t] = max(errs)
+        except Exception as e:  # noqa: BLE001
+            results[t] = e
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for r in results:
+        assert not isinstance(r, Exception), r
+        assert r <= REL_TOL
