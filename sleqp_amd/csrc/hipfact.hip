@@ -323,7 +323,10 @@ static int upload_plan(hipfact_handle* h) {
       int with_children = 0;
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q)
         with_children += (P.child_ptr[P.level_sn[q] + 1] > P.child_ptr[P.level_sn[q]]);
+      // workgroups per front: enough to fill the chip for few fronts, and one per ~16 target
+      // columns for very large fronts (dense Schur complements copy tens of MB per level)
       li.nparts = with_children > 0 ? std::max(1, std::min(32, 768 / with_children)) : 1;
+      if (with_children > 0 && mr >= 1024) li.nparts = std::max(li.nparts, std::min(256, mr / 16));
       li.itA = (long long)items.size();
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
         const int s = P.level_sn[q];
