@@ -799,9 +799,14 @@ __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn,
   dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
 }
 
-// backward step of one front (lds: u + w doubles)
+__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info);
+
+// backward step of one front (lds: u + w doubles).  In the single-launch top-of-tree
+// kernel (flags != nullptr) the wait for the parent happens AFTER the panel
+// fragments have been requested, so their latency overlaps the dependency wait.
 __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __restrict__ L,
-                                              const int* __restrict__ rows, double* __restrict__ y, double* lds) {
+                                              const int* __restrict__ rows, double* __restrict__ y, double* lds,
+                                              int* __restrict__ flags = nullptr, int* __restrict__ info = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = S.w, r = S.r, u = r - w;
   const double* __restrict__ P = L + S.Loff;
@@ -823,6 +828,7 @@ __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __r
         lv[p][c][q] = (pre && k < w && a < u) ? col[w + a] : 0.0;
       }
     }
+  if (flags && S.parent >= 0) top_wait(flags, S.parent, info);  // the parent is done only after all its ancestors
   for (int a = tid; a < u; a += SB) g[a] = y[rw[a]];
   __syncthreads();
   // v_k = z_k / d_k - L21(:,k)^T g
@@ -977,8 +983,7 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = top_sn[blockIdx.x];
   const SnDesc S = sn[s];
-  if (S.parent >= 0) top_wait(flags, S.parent, info);  // the parent is done only after all its ancestors
-  dev_bwd_front(S, L, rows, y, lds);
+  dev_bwd_front(S, L, rows, y, lds, flags, info);
   top_publish(flags, s);
 }
 
