@@ -317,7 +317,7 @@ static int upload_plan(hipfact_handle* h) {
     li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
     // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
-    li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5) && mu > 0;
+    li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5);
     {
       // assembly items: (front, target-column class) for every front that has children
       int with_children = 0;

@@ -466,51 +466,28 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
     d4_t acc[8];
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    double pv[4], pn[4];
+    // all fragments of the 16 panel rows in one batch of loads (w <= 128: 32 values per lane)
+    double pv[8][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int col = 4 * s + lk;
-      pv[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
-    }
-#pragma unroll 1
-    for (int tt = 0; tt < nbk; ++tt) {
-      if (tt + 1 < nbk) {
+    for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int col = 16 * (tt + 1) + 4 * s + lk;
-          pn[s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
-        }
+      for (int s = 0; s < 4; ++s) {
+        const int col = 16 * tt + 4 * s + lk;
+        pv[tt][s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
       }
-      if (X_IN_LDS) {
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt)
+      if (tt < nbk) {
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
           if (ct >= tt && ct < nbk) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
-              acc[ct] = MFMA_F64(xv, pv[s], acc[ct]);
+              acc[ct] = MFMA_F64(xv, pv[tt][s], acc[ct]);
             }
-          }
-      } else {
-        // X(i, k) for i > k from the panel top, unit diagonal, zero above
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-          if (ct >= tt && ct < nbk) {
-            double xv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const int i = 16 * ct + li, k = 16 * tt + 4 * s + lk;
-              double v = (i == k) ? 1.0 : 0.0;
-              if (i < w && i > k) v = P[i + (long long)k * r];
-              xv[s] = v;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[ct] = MFMA_F64(xv[s], pv[s], acc[ct]);
           }
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) pv[s] = pn[s];
-    }
     if (rok) {
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct)
@@ -546,6 +523,19 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  // the assembled U tile is fetched up front so that its latency hides behind the operand staging
+  double uv[2][2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int i = 64 * I + i0 + 16 * y + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
+        uv[x][y][q] = (!assign && !idle && i < u && j < u && i >= j) ? c.Us[i + (long long)j * u] : 0.0;
+      }
+    }
   const int si = tid & 63;
   const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
   const double* __restrict__ pi = P21 + 64 * I + si;
@@ -607,8 +597,7 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
       for (int q = 0; q < 4; ++q) {
         const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
         if (i < u && j < u && i >= j) {
-          double* dst = c.Us + i + (long long)j * u;
-          *dst = assign ? -acc[x][y][q] : *dst - acc[x][y][q];
+          c.Us[i + (long long)j * u] = uv[x][y][q] - acc[x][y][q];
         }
       }
     }
