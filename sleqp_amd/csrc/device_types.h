@@ -23,7 +23,28 @@ struct SnDesc {
   int child_begin;   // children in child_idx[child_begin, child_end)
   int child_end;
   int pad0;  // elimination-tree level of the front
-  int pad1;
+  int pad1;  // offset of this front's inverse relative indices (as a child) in inv[]
+};
+
+// children of a front, flattened for the pull-mode extend-add (one uniform load per workgroup)
+constexpr int MAXCH = 4;
+struct PullDesc {
+  long long Uoff[MAXCH];    // child's update matrix
+  long long reloff[MAXCH];  // child's relative indices
+  int invoff[MAXCH];        // child's inverse relative indices (SnDesc::pad1)
+  int uc[MAXCH];            // order of the child's update matrix
+  int n;                    // number of children, -1 if more than MAXCH
+  int pad[3];
+};
+
+// one workgroup of a split-phase kernel: everything it needs in ONE uniform load (a dependent
+// walk items -> descriptor -> children costs a memory round trip per hop on the critical path)
+struct FrontItem {
+  long long Loff, Uoff;
+  int w, r;
+  int part;    // panel row block / (I << 16 | J) tile / unused
+  int nchild;  // children of the front (assign-mode Schur update when 0)
+  PullDesc pd;
 };
 
 // info words written by the factorisation kernels

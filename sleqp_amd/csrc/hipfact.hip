@@ -72,9 +72,12 @@ struct LevelInfo {
   size_t lds_factor = 0, lds_fwd = 0, lds_bwd = 0;
   // split mode (few, large fronts): one kernel per phase, many workgroups per front
   bool split = false;
+  bool pull = false;  // split kernels gather the children's updates themselves (no phase A launch)
   int nparts = 1;
-  long long itA = 0, itC = 0, itD = 0;  // offsets (in ints) into d_items
+  long long itA = 0;                    // offset (in ints) into d_items
+  long long itB = 0, itC = 0, itD = 0;  // offsets (in FrontItems) into d_fitems
   int nA = 0, nC = 0, nD = 0;           // number of (front, part) items
+  int panel_threads = 512;              // 16 panel rows per wave
   size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0, lds_asm = 0;
 };
 
@@ -125,6 +128,8 @@ struct hipfact_handle {
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 1 << 30;
+  int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
+  int pull_max_children = 4;  // <= MAXCH; 0: always the separate assembly kernel
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
@@ -135,7 +140,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_top_sn, d_flags;
+  DevBuf d_items, d_fitems, d_top_sn, d_flags, d_inv;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -240,7 +245,44 @@ static int upload_plan(hipfact_handle* h) {
     d.pad0 = P.sn_level[s];
     d.pad1 = 0;
   }
+  // inverse relative indices for the pull-mode extend-add: for child s with parent p,
+  // inv[pad1(s) + q] = row of s's update matrix that lands on front row q of p, or -1
+  std::vector<int> inv;
+  {
+    long long total = 0;
+    for (int s = 0; s < ns; ++s)
+      if (P.sn_parent[s] >= 0) total += P.sn_r[P.sn_parent[s]];
+    if (total >= (1LL << 31)) {
+      h->error = "inverse index map exceeds 2^31 entries";
+      return HIPFACT_EINTERNAL;
+    }
+    inv.assign((size_t)total, -1);
+    long long off = 0;
+    for (int s = 0; s < ns; ++s) {
+      const int p = P.sn_parent[s];
+      if (p < 0) continue;
+      sn[s].pad1 = (int)off;
+      const int us = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
+      for (int a = 0; a < us; ++a) inv[(size_t)off + P.rel[P.rel_ptr[s] + a]] = a;
+      off += P.sn_r[p];
+    }
+  }
+  std::vector<PullDesc> pulls(ns);
+  for (int s = 0; s < ns; ++s) {
+    PullDesc& pd = pulls[s];
+    memset(&pd, 0, sizeof(pd));
+    const int nch = P.child_ptr[s + 1] - P.child_ptr[s];
+    pd.n = nch <= MAXCH ? nch : -1;
+    for (int k = 0; k < nch && nch <= MAXCH; ++k) {
+      const int ch = P.child_idx[P.child_ptr[s] + k];
+      pd.Uoff[k] = sn[ch].Uoff;
+      pd.reloff[k] = sn[ch].reloff;
+      pd.invoff[k] = sn[ch].pad1;
+      pd.uc[k] = sn[ch].r - sn[ch].w;
+    }
+  }
   int rc;
+  if ((rc = upload(h, h->d_inv, inv))) return rc;
   if ((rc = upload(h, h->d_sn, sn))) return rc;
   if ((rc = upload(h, h->d_level_sn, P.level_sn))) return rc;
   if ((rc = upload(h, h->d_rows, P.sn_rows))) return rc;
@@ -291,14 +333,16 @@ static int upload_plan(hipfact_handle* h) {
   h->levels.assign(P.nlevels, LevelInfo());
   size_t max_lds = 0;
   std::vector<int> items;
+  std::vector<FrontItem> fitems;
   for (int l = 0; l < P.nlevels; ++l) {
     LevelInfo& li = h->levels[l];
     li.begin = P.level_ptr[l];
     li.count = P.level_ptr[l + 1] - P.level_ptr[l];
-    int mw = 0, mr = 0, mu = 0;
+    int mw = 0, mr = 0, mu = 0, mch = 0;
     double work = 0;
     for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
       const int s = P.level_sn[q];
+      mch = std::max(mch, P.child_ptr[s + 1] - P.child_ptr[s]);
       const int w = P.sn_c0[s + 1] - P.sn_c0[s], r = P.sn_r[s];
       mw = std::max(mw, w);
       mr = std::max(mr, r);
@@ -309,8 +353,8 @@ static int upload_plan(hipfact_handle* h) {
     const size_t needB = wp * (wp + 1) + 16 * (wp + 1) + 32;
     const size_t needD = (size_t)128 * 64;  // two 64 x 64 operand strips
     li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
-    li.lds_pivot = (wp + needB) * sizeof(double);
-    li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double);
+    li.lds_pivot = (wp + needB) * sizeof(double) + MAXCH * wp * sizeof(int);
+    li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double) + MAXCH * wp * sizeof(int);
     li.lds_schur = (wp + needD) * sizeof(double);
     li.lds_asm = ((size_t)P.max_u + 16) * sizeof(int);
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
@@ -318,6 +362,7 @@ static int upload_plan(hipfact_handle* h) {
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
     // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
     li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5);
+    li.pull = li.split && mch > 0 && mch <= std::min(h->pull_max_children, MAXCH);
     {
       // assembly items: (front, target-column class) for every front that has children
       int with_children = 0;
@@ -339,26 +384,47 @@ static int upload_plan(hipfact_handle* h) {
       }
     }
     if (li.split) {
-      li.itC = (long long)items.size();
+      auto item = [&](int s, int part) {
+        FrontItem it;
+        memset(&it, 0, sizeof(it));
+        it.Loff = sn[s].Loff;
+        it.Uoff = sn[s].Uoff;
+        it.w = sn[s].w;
+        it.r = sn[s].r;
+        it.part = part;
+        it.nchild = sn[s].child_end - sn[s].child_begin;
+        it.pd = pulls[s];
+        return it;
+      };
+      li.itB = (long long)fitems.size();
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) fitems.push_back(item(P.level_sn[q], 0));
+      li.itC = (long long)fitems.size();
+      {
+        // 128 panel rows per workgroup (8 waves); 64 when that leaves most of the chip idle
+        long long blocks128 = 0;
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          blocks128 += (P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]) + 127) / 128;
+        }
+        li.panel_threads = (blocks128 < h->panel_small_below) ? 256 : 512;
+      }
+      const int prow = li.panel_threads / 4;
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
         const int s = P.level_sn[q];
         const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
-        for (int b = 0; b < (u + 127) / 128; ++b) {  // 128 panel rows per workgroup (8 waves)
-          items.push_back(s);
-          items.push_back(b);
+        for (int b = 0; b < (u + prow - 1) / prow; ++b) {
+          fitems.push_back(item(s, b));
           ++li.nC;
         }
       }
-      li.itD = (long long)items.size();
-      // heaviest strips first is irrelevant here: every tile costs the same
+      li.itD = (long long)fitems.size();
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
         const int s = P.level_sn[q];
         const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
         const int nt = (u + 63) / 64;
         for (int I = 0; I < nt; ++I)
           for (int J = 0; J <= I; ++J) {
-            items.push_back(s);
-            items.push_back((I << 16) | J);
+            fitems.push_back(item(s, (I << 16) | J));
             ++li.nD;
           }
       }
@@ -374,6 +440,7 @@ static int upload_plan(hipfact_handle* h) {
       (h->levels[l].split ? h->rows_split : h->rows_fused) += r;
     }
   if ((rc = upload(h, h->d_items, items))) return rc;
+  if ((rc = upload(h, h->d_fitems, fitems))) return rc;
   {
     // levels merged into the single-launch top-of-tree solve: as many of the last levels as fit
     // the co-residency cap, and only if that saves at least two launches
@@ -462,18 +529,20 @@ static int factor_enqueue(hipfact_handle* h) {
   for (int l = 0; l < P.nlevels; ++l) {
     const LevelInfo& li = h->levels[l];
     const int* it = h->d_items.as<int>();
-    if (li.nA > 0 && (h->debug_phases & 1))
+    const int pull = (li.pull && h->debug_phases == 15) ? 1 : 0;
+    if (li.nA > 0 && (h->debug_phases & 1) && !pull)
       LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), li.lds_asm, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
              h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
     if (li.split && h->debug_phases == 15) {
-      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(512), li.lds_pivot, h->d_sn.as<SnDesc>(),
-             h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>());
+      const FrontItem* fit = h->d_fitems.as<FrontItem>();
+      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(512), li.lds_pivot, fit + li.itB, h->d_L.as<double>(),
+             h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
       if (li.nC > 0)
-        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(512), li.lds_panel, h->d_sn.as<SnDesc>(), it + li.itC,
-               h->d_L.as<double>(), h->d_U.as<double>());
+        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(li.panel_threads), li.lds_panel, fit + li.itC,
+               h->d_L.as<double>(), h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
       if (li.nD > 0)
-        LAUNCH(PC_FACTOR_D, k_front_schur, dim3(li.nD), dim3(FB), li.lds_schur, h->d_sn.as<SnDesc>(), it + li.itD,
-               h->d_L.as<double>(), h->d_U.as<double>());
+        LAUNCH(PC_FACTOR_D, k_front_schur, dim3(li.nD), dim3(FB), li.lds_schur, fit + li.itD, h->d_L.as<double>(),
+               h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
     } else {
       LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
              h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(),
@@ -769,6 +838,8 @@ int hipfact_create(hipfact_handle** out, int device) {
   }
   if (const char* s = getenv("HIPFACT_REFINE")) h->refine_steps = atoi(s);
   if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
+  if (const char* s = getenv("HIPFACT_PULL_MAX")) h->pull_max_children = atoi(s);
+  if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
   *out = h;
@@ -1317,6 +1388,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "top_max_fronts")) {  // 0 disables the single-launch top-of-tree solve
     h->top_max_fronts = (int)value;
+    drop_graphs(h);
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "pull_max_children")) {  // 0: extend-add always through the separate assembly kernel
+    h->pull_max_children = (int)value;
     drop_graphs(h);
     h->have_plan = false;
     h->factored = false;

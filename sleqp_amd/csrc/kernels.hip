@@ -126,7 +126,8 @@ struct FrontCtx {
   double* Yp;  // block-column panel (LDS)
 };
 
-__device__ __forceinline__ FrontCtx make_ctx(const SnDesc& S, double* L, double* U, double* lds) {
+template <class Desc>
+__device__ __forceinline__ FrontCtx make_ctx(const Desc& S, double* L, double* U, double* lds) {
   FrontCtx c;
   c.w = S.w;
   c.r = S.r;
@@ -140,6 +141,40 @@ __device__ __forceinline__ FrontCtx make_ctx(const SnDesc& S, double* L, double*
   c.A = lds + c.wp;
   c.Yp = c.A + c.wp * c.lda;
   return c;
+}
+
+// ---- pull-mode extend-add (split kernels).  Instead of a separate assembly pass
+// that scatters the children's update matrices into the parent (phase A), the
+// phases B / C / D of the parent gather the contributions of element (i, j)
+// themselves: inv_c[p] = row of child c's update matrix that maps to front row p
+// (-1: none).  Children are added in child order on top of the original entry,
+// which is exactly the order of dev_assemble: both paths give identical bits.
+struct PullCtx {
+  int n;
+  const double* Uc[MAXCH];
+  const int* inv[MAXCH];
+  const int* rel[MAXCH];
+  int uc[MAXCH];
+};
+
+__device__ __forceinline__ PullCtx make_pull(const PullDesc& D, const double* __restrict__ U,
+                                             const int* __restrict__ inv, const int* __restrict__ rel, int pull) {
+  PullCtx pc;
+  pc.n = pull ? D.n : 0;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    pc.Uc[ch] = nullptr;
+    pc.inv[ch] = nullptr;
+    pc.rel[ch] = nullptr;
+    pc.uc[ch] = 0;
+    if (ch < pc.n) {
+      pc.Uc[ch] = U + D.Uoff[ch];
+      pc.inv[ch] = inv + D.invoff[ch];
+      pc.rel[ch] = rel + D.reloff[ch];
+      pc.uc[ch] = D.uc[ch];
+    }
+  }
+  return pc;
 }
 
 // ---- phase A (any block size).  Fronts without children are not assembled at
@@ -277,7 +312,7 @@ __device__ __forceinline__ void dev_trailing_tile(const FrontCtx& c, int k0, int
 // Blocked right-looking LDL^T (nb = 16) with look-ahead: in the trailing update of
 // step kb, wave 0 updates the next diagonal tile first and factors it at once,
 // while the other waves finish the remaining tiles.  Any number of waves >= 1.
-__device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases = 15) {
+__device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -287,22 +322,75 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   double* Yp = c.Yp;
   double* scratch = Yp + 16 * lda;  // 32 doubles for the diagonal-block micro-kernel
   const double* __restrict__ P = c.P;
-  // eight columns per batch so that the panel loads are in flight together
-  for (int kk = wave; kk < wp; kk += 8 * nw)
-    for (int i = lane; i < wp; i += 64) {
-      double v[8];
+  if (pc.n > 0) {
+    // pull-mode extend-add (8 waves, wp <= 128: the whole block is one batch of 2 x 16 entries
+    // per thread).  Order of issue = order of the dependent round trips: the children's inverse
+    // maps of the pivot rows and the panel entries leave together; the maps go through LDS;
+    // then all gathers leave together.  Children are added in child order on top of the
+    // original entry, as dev_assemble does.
+    int* invb = reinterpret_cast<int*>(scratch + 32);
+    int iv[MAXCH];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = kk + nw * q;
-        v[q] = (i == k) ? 1.0 : 0.0;
-        if (i < w && k < w) v[q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
+    for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < pc.n && tid < w) ? pc.inv[ch][tid] : -1;
+    double v[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = lane + 64 * t, k = wave + 8 * q;
+        v[t][q] = (i == k) ? 1.0 : 0.0;
+        if (i < w && k < w) v[t][q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = kk + nw * q;
-        if (k < wp) A[i + k * lda] = v[q];
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n && tid < wp) invb[ch * wp + tid] = iv[ch];
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n) {
+        const double* __restrict__ Uc = pc.Uc[ch];
+        const int uc = pc.uc[ch];
+        const int* ib = invb + ch * wp;
+        int ci[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = wave + 8 * q;
+          const int ck = (k < wp) ? ib[k] : -1;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
+            const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
+            v[t][q] += ok ? g : 0.0;
+          }
+        }
       }
-    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = lane + 64 * t, k = wave + 8 * q;
+        if (i < wp && k < wp) A[i + k * lda] = v[t][q];
+      }
+  } else {
+    // eight columns per batch so that the panel loads are in flight together
+    for (int kk = wave; kk < wp; kk += 8 * nw)
+      for (int i = lane; i < wp; i += 64) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = kk + nw * q;
+          v[q] = (i == k) ? 1.0 : 0.0;
+          if (i < w && k < w) v[q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = kk + nw * q;
+          if (k < wp) A[i + k * lda] = v[q];
+        }
+      }
+  }
   __syncthreads();
   if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
   __syncthreads();
@@ -453,7 +541,8 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
 // the finished panel top in L2 (split kernel: no LDS, no barrier, full
 // occupancy); results are stored row-contiguous.  Row blocks blk, blk + stride.
 template <bool X_IN_LDS>
-__device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride) {
+__device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride, const PullCtx& pc,
+                                                const int* invl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
@@ -474,6 +563,31 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
       for (int s = 0; s < 4; ++s) {
         const int col = 16 * tt + 4 * s + lk;
         pv[tt][s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
+      }
+    int cis[MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) cis[ch] = (ch < pc.n && rok) ? pc.inv[ch][R0 + li] : -1;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n) {
+        // unconditional loads (clamped to entry 0) so that they all leave in one batch
+        const int ci = cis[ch];
+        const double* __restrict__ Uc = pc.Uc[ch];
+        const int uc = pc.uc[ch];
+        double g[8][4];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int col = 16 * tt + 4 * s + lk;
+            const int cj = (tt < nbk && ci >= 0) ? invl[ch * c.wp + col] : -1;
+            const double gv = Uc[(cj >= 0) ? ci + (long long)cj * uc : 0];
+            g[tt][s] = (cj >= 0) ? gv : 0.0;
+          }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) pv[tt][s] += g[tt][s];
       }
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt)
@@ -510,7 +624,8 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 // that two workgroups share a CU and hide each other's staging latency.
 constexpr int KC = 64;
 template <bool DD_IN_LDS>
-__device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign) {
+__device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign,
+                                               const PullCtx& pc) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, u = c.u;
@@ -533,9 +648,52 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
-        uv[x][y][q] = (!assign && !idle && i < u && j < u && i >= j) ? c.Us[i + (long long)j * u] : 0.0;
+        uv[x][y][q] = (!assign && !idle && pc.n == 0 && i < u && j < u && i >= j) ? c.Us[i + (long long)j * u] : 0.0;
       }
     }
+  if (!idle && pc.n > 0) {
+    int ci[MAXCH][2], cj[MAXCH][2][4];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const int i = 64 * I + i0 + 16 * y + li;
+        ci[ch][y] = (ch < pc.n && i < u) ? pc.inv[ch][w + i] : -1;
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
+          cj[ch][x][q] = (ch < pc.n && j < u) ? pc.inv[ch][w + j] : -1;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n) {
+        const double* __restrict__ Uc = pc.Uc[ch];
+        const int uc = pc.uc[ch];
+        double g[2][2][4];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              // rel is monotone: i >= j in the front implies ci >= cj in the child; loads are
+              // unconditional (clamped to entry 0) so that they all leave in one batch
+              const bool ok = ci[ch][y] >= 0 && cj[ch][x][q] >= 0 && ci[ch][y] >= cj[ch][x][q];
+              const double gv = Uc[ok ? ci[ch][y] + (long long)cj[ch][x][q] * uc : 0];
+              g[x][y][q] = ok ? gv : 0.0;
+            }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) uv[x][y][q] += g[x][y][q];
+      }
+  }
   const int si = tid & 63;
   const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
   const double* __restrict__ pi = P21 + 64 * I + si;
@@ -615,21 +773,23 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
   const SnDesc S = sn[level_sn[blockIdx.x]];
   const FrontCtx c = make_ctx(S, L, U, lds);
   if (!(phases & 2)) return;
-  dev_pivot_block(c, info, phases);
+  PullCtx nopull;
+  nopull.n = 0;
+  dev_pivot_block(c, info, phases, nopull);
   dev_store_pivot_block(c);
   if (!(phases & 4)) return;
-  dev_panel_solve<true>(c, 0, 1);
+  dev_panel_solve<true>(c, 0, 1, nopull, nullptr);
   __syncthreads();
   if (c.u > 0 && (phases & 8)) {
     double* SI = c.A;
     double* SJ = c.A + 64 * KC;
     const int nt = (c.u + 63) >> 6;
     for (int I = 0; I < nt; ++I)
-      for (int J = 0; J <= I; ++J) dev_schur_tile<true>(c, SI, SJ, I, J, S.child_begin == S.child_end);
+      for (int J = 0; J <= I; ++J) dev_schur_tile<true>(c, SI, SJ, I, J, S.child_begin == S.child_end, nopull);
   }
 }
 
-// split kernels: items[2 * blockIdx.x] = supernode, items[2 * blockIdx.x + 1] = part
+// phase A as its own kernel: items[2 * blockIdx.x] = supernode, items[2 * blockIdx.x + 1] = part
 __global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restrict__ sn, const int* __restrict__ items,
                                                        int nparts, double* __restrict__ L, double* __restrict__ U,
                                                        const int* __restrict__ rel,
@@ -640,33 +800,46 @@ __global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restric
   dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts, reinterpret_cast<int*>(lds));
 }
 
-__global__ __launch_bounds__(512) void k_front_pivot(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
-                                                    double* __restrict__ L, double* __restrict__ U,
-                                                    int* __restrict__ info) {
+// split kernels B / C / D: one self-contained FrontItem per workgroup
+__global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict__ items, double* __restrict__ L,
+                                                    double* __restrict__ U, int* __restrict__ info,
+                                                    const int* __restrict__ inv, const int* __restrict__ rel,
+                                                    int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const SnDesc S = sn[level_sn[blockIdx.x]];
+  const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
-  dev_pivot_block(c, info);
+  const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
+  dev_pivot_block(c, info, 15, pc);
   dev_store_pivot_block(c);
 }
 
-__global__ __launch_bounds__(512) void k_front_panel(const SnDesc* __restrict__ sn, const int* __restrict__ items,
-                                                    double* __restrict__ L, double* __restrict__ U) {
+// LDS: dd | X | MAXCH x wp ints (the children's inverse maps of the pivot columns)
+__global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict__ items, double* __restrict__ L,
+                                                    double* __restrict__ U, const int* __restrict__ inv,
+                                                    const int* __restrict__ rel, int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const SnDesc S = sn[items[2 * blockIdx.x]];
+  const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
+  const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
+  int* invl = reinterpret_cast<int*>(c.A + c.wp * c.lda);
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n)
+      for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
   dev_load_pivot_block(c, true);
-  dev_panel_solve<true>(c, items[2 * blockIdx.x + 1], 1 << 20);
+  dev_panel_solve<true>(c, S.part, 1 << 20, pc, invl);
 }
 
-// items: supernode, (I << 16) | J
-__global__ __launch_bounds__(FB) void k_front_schur(const SnDesc* __restrict__ sn, const int* __restrict__ items,
-                                                    double* __restrict__ L, double* __restrict__ U) {
+// part = (I << 16) | J
+__global__ __launch_bounds__(FB) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
+                                                    double* __restrict__ U, const int* __restrict__ inv,
+                                                    const int* __restrict__ rel, int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const SnDesc S = sn[items[2 * blockIdx.x]];
+  const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
-  const int ij = items[2 * blockIdx.x + 1];
-  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.child_begin == S.child_end);
+  const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
+  const int ij = S.part;
+  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc);
 }
 
 // ---------------------------------------------------------------------------

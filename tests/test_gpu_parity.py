@@ -314,6 +314,27 @@ def test_determinism(fact):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("kind,n,m", [("b", 6000, 3000), ("u", 1500, 700)])
+def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
+    """The two extend-add paths (separate assembly kernel / gather inside the pivot, panel and
+    Schur kernels) add the children's contributions in the same order: identical bits."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(n, m, kind, 0.02, 11)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    b = np.random.default_rng(1).standard_normal(N)
+    fact.set_option("refine_steps", 0)
+    outs = []
+    for pull in (0, 4, 2):
+        fact.set_option("pull_max_children", pull)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    assert scaled_residual(K, outs[0], b) <= 1e-9
+
+
 @pytest.mark.parametrize("workload", ["banded_n1e5_m5e4", "uniform_n1e4_m5e3"])
 def test_full_size_properties(fact, workload):
     """BASELINE.json configs[3] / configs[2] at full size: properties that do not need the dense oracle."""
