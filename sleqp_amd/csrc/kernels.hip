@@ -540,82 +540,103 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
 // the A operand is X = inv(L11), read from LDS (fused kernel) or straight from
 // the finished panel top in L2 (split kernel: no LDS, no barrier, full
 // occupancy); results are stored row-contiguous.  Row blocks blk, blk + stride.
+// rows R0 + li of the panel: all fragments in one batch of loads (w <= 128: 32 values per lane),
+// plus the children's rows that land on them (pull mode)
+__device__ __forceinline__ void dev_panel_rows_load(const FrontCtx& c, int R0, const PullCtx& pc, double (&pv)[8][4],
+                                                    int (&cis)[MAXCH]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r;
+  const bool rok = (R0 + li) < r;
+  const double* __restrict__ Prow = c.P + R0 + li;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) cis[ch] = (ch < pc.n && rok) ? pc.inv[ch][R0 + li] : -1;
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int col = 16 * tt + 4 * s + lk;
+      pv[tt][s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
+    }
+}
+
+// gathers (pull mode), X P21^T on the MFMA units, scaling by D^-1, row-contiguous stores
 template <bool X_IN_LDS>
-__device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride, const PullCtx& pc,
-                                                const int* invl) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0, const PullCtx& pc, const int* invl,
+                                                      double (&pv)[8][4], const int (&cis)[MAXCH]) {
+  const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
   const double* A = c.A;
   double* __restrict__ P = c.P;
-  const int RB = 16 * (blockDim.x >> 6);  // panel rows per workgroup pass
-  for (int R0 = w + RB * blk + 16 * wave; R0 < r; R0 += RB * blk_stride) {
-    const bool rok = (R0 + li) < r;
-    const double* __restrict__ Prow = P + R0 + li;
-    d4_t acc[8];
+  const bool rok = (R0 + li) < r;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    // all fragments of the 16 panel rows in one batch of loads (w <= 128: 32 values per lane)
-    double pv[8][4];
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n) {
+      // unconditional loads (clamped to entry 0) so that they all leave in one batch
+      const int ci = cis[ch];
+      const double* __restrict__ Uc = pc.Uc[ch];
+      const int uc = pc.uc[ch];
+      double g[8][4];
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt)
+      for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int col = 16 * tt + 4 * s + lk;
-        pv[tt][s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
-      }
-    int cis[MAXCH];
+        for (int s = 0; s < 4; ++s) {
+          const int col = 16 * tt + 4 * s + lk;
+          const int cj = (tt < nbk && ci >= 0) ? invl[ch * c.wp + col] : -1;
+          const double gv = Uc[(cj >= 0) ? ci + (long long)cj * uc : 0];
+          g[tt][s] = (cj >= 0) ? gv : 0.0;
+        }
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) cis[ch] = (ch < pc.n && rok) ? pc.inv[ch][R0 + li] : -1;
+      for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < pc.n) {
-        // unconditional loads (clamped to entry 0) so that they all leave in one batch
-        const int ci = cis[ch];
-        const double* __restrict__ Uc = pc.Uc[ch];
-        const int uc = pc.uc[ch];
-        double g[8][4];
+        for (int s = 0; s < 4; ++s) pv[tt][s] += g[tt][s];
+    }
+  d4_t acc[8];
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
+  for (int ct = 0; ct < 8; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int col = 16 * tt + 4 * s + lk;
-            const int cj = (tt < nbk && ci >= 0) ? invl[ch * c.wp + col] : -1;
-            const double gv = Uc[(cj >= 0) ? ci + (long long)cj * uc : 0];
-            g[tt][s] = (cj >= 0) ? gv : 0.0;
-          }
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) pv[tt][s] += g[tt][s];
-      }
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt)
-      if (tt < nbk) {
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-          if (ct >= tt && ct < nbk) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
-              acc[ct] = MFMA_F64(xv, pv[tt][s], acc[ct]);
-            }
-          }
-      }
-    if (rok) {
+  for (int tt = 0; tt < 8; ++tt)
+    if (tt < nbk) {
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct)
-        if (ct < nbk) {
+        if (ct >= tt && ct < nbk) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int col = 16 * ct + lk + 4 * q;
-            if (col < w) {
-              const double dcol = X_IN_LDS ? c.dd[col] : P[col + (long long)col * r];
-              P[(R0 + li) + (long long)col * r] = acc[ct][q] / dcol;
-            }
+          for (int s = 0; s < 4; ++s) {
+            const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
+            acc[ct] = MFMA_F64(xv, pv[tt][s], acc[ct]);
           }
         }
     }
+  if (rok) {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+      if (ct < nbk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 16 * ct + lk + 4 * q;
+          if (col < w) {
+            const double dcol = X_IN_LDS ? c.dd[col] : P[col + (long long)col * r];
+            P[(R0 + li) + (long long)col * r] = acc[ct][q] / dcol;
+          }
+        }
+      }
+  }
+}
+
+// ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
+// rows: the B operand streams from the panel (16 consecutive rows per k-step),
+// the A operand is X = inv(L11) in LDS.  Row blocks blk, blk + stride, ...
+template <bool X_IN_LDS>
+__device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride, const PullCtx& pc,
+                                                const int* invl) {
+  const int wave = threadIdx.x >> 6;
+  const int RB = 16 * (blockDim.x >> 6);  // panel rows per workgroup pass
+  for (int R0 = c.w + RB * blk + 16 * wave; R0 < c.r; R0 += RB * blk_stride) {
+    double pv[8][4];
+    int cis[MAXCH];
+    dev_panel_rows_load(c, R0, pc, pv, cis);
+    dev_panel_rows_finish<X_IN_LDS>(c, R0, pc, invl, pv, cis);
   }
 }
 
@@ -826,12 +847,17 @@ __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict
   for (int ch = 0; ch < MAXCH; ++ch)
     if (ch < pc.n)
       for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
+  // this wave's 16 panel rows leave for the registers before X is staged: one round trip for both
+  const int R0 = c.w + 16 * (blockDim.x >> 6) * S.part + 16 * (threadIdx.x >> 6);
+  double pv[8][4];
+  int cis[MAXCH];
+  dev_panel_rows_load(c, R0, pc, pv, cis);
   dev_load_pivot_block(c, true);
-  dev_panel_solve<true>(c, S.part, 1 << 20, pc, invl);
+  if (R0 < c.r) dev_panel_rows_finish<true>(c, R0, pc, invl, pv, cis);
 }
 
 // part = (I << 16) | J
-__global__ __launch_bounds__(FB) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
+__global__ __launch_bounds__(FB, 2) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
                                                     double* __restrict__ U, const int* __restrict__ inv,
                                                     const int* __restrict__ rel, int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
