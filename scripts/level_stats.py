@@ -30,3 +30,6 @@ nch = np.diff(p.child_ptr)
 for l in range(p.nlevels):
     s = np.where(lev == l)[0]
     print(f"level {l:2d} children per front: mean {nch[s].mean():5.2f} max {nch[s].max():3d}  hist {np.bincount(nch[s], minlength=6)[:8]}")
+print(f"nM {len(p.Mi)} nprod {p.nprod} avg products per entry {p.nprod / max(len(p.Mi), 1):.2f} nnzK {p.nnzK}")
+pl = np.diff(p.prod_ptr)
+print("products per entry: hist", np.bincount(np.minimum(pl, 12)))

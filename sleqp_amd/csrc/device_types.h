@@ -47,6 +47,22 @@ struct FrontItem {
   PullDesc pd;
 };
 
+// one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)
+struct TopItem {
+  long long Loff, uoff, rowoff;
+  int s, c0, w, r, parent;
+  int nchild;              // -1: more than MAXCH children (generic path through the SnDesc walk)
+  int prefetch;            // bit 0 / 1: the forward / backward step prefetches (buffers fit the LDS)
+  int pad;
+  long long c_uoff[MAXCH];   // children's update vectors
+  long long c_reloff[MAXCH]; // children's relative indices
+  int c_uc[MAXCH];
+  int c_id[MAXCH];
+  int c_wait[MAXCH];         // child is part of the same launch: wait for its flag
+};
+constexpr int TOP_REL_CAP = 2048;   // ints of children's relative indices staged in LDS
+constexpr int TOP_L21_CAP = 16384;  // doubles of L21 (forward) / inv(L11) (backward) staged in LDS
+
 // info words written by the factorisation kernels
 enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_TIMEOUT = 2, INFO_WORDS = 4 };
 

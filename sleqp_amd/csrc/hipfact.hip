@@ -128,6 +128,7 @@ struct hipfact_handle {
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 1 << 30;
+  int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
   int pull_max_children = 4;  // <= MAXCH; 0: always the separate assembly kernel
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
@@ -140,7 +141,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_fitems, d_top_sn, d_flags, d_inv;
+  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -452,13 +453,51 @@ static int upload_plan(hipfact_handle* h) {
       h->top_level = lvl;
       h->top_count = total;
       std::vector<int> top;
+      std::vector<TopItem> titems;
       h->top_lds_fwd = h->top_lds_bwd = 0;
       for (int l = lvl; l < P.nlevels; ++l) {
-        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) top.push_back(P.level_sn[q]);
-        h->top_lds_fwd = std::max(h->top_lds_fwd, h->levels[l].lds_fwd);
-        h->top_lds_bwd = std::max(h->top_lds_bwd, h->levels[l].lds_bwd);
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          top.push_back(s);
+          TopItem T;
+          memset(&T, 0, sizeof(T));
+          T.Loff = sn[s].Loff;
+          T.uoff = sn[s].uoff;
+          T.rowoff = sn[s].rowoff;
+          T.s = s;
+          T.c0 = sn[s].c0;
+          T.w = sn[s].w;
+          T.r = sn[s].r;
+          T.parent = sn[s].parent;
+          const int nch = sn[s].child_end - sn[s].child_begin;
+          const long long u = T.r - T.w;
+          long long sum_uc = 0;
+          T.nchild = nch <= MAXCH ? nch : -1;
+          for (int k = 0; k < nch && nch <= MAXCH; ++k) {
+            const int ch = P.child_idx[sn[s].child_begin + k];
+            T.c_uoff[k] = sn[ch].uoff;
+            T.c_reloff[k] = sn[ch].reloff;
+            T.c_uc[k] = sn[ch].r - sn[ch].w;
+            T.c_id[k] = ch;
+            T.c_wait[k] = P.sn_level[ch] >= lvl;
+            sum_uc += T.c_uc[k];
+          }
+          size_t lf = h->levels[l].lds_fwd, lb = h->levels[l].lds_bwd;
+          if (h->top_prefetch && T.nchild >= 0 && sum_uc <= TOP_REL_CAP && u * T.w <= TOP_L21_CAP) {
+            T.prefetch |= 1;
+            lf = ((size_t)T.r + 9 * (size_t)T.w + 1024 + TOP_REL_CAP / 2 + (size_t)(u * T.w) + 2) * sizeof(double);
+          }
+          if (h->top_prefetch && u <= 256) {
+            T.prefetch |= 2;
+            lb = ((size_t)u + 3 * (size_t)T.w + (size_t)((u + 1) / 2) + (size_t)T.w * T.w + 2) * sizeof(double);
+          }
+          h->top_lds_fwd = std::max(h->top_lds_fwd, lf);
+          h->top_lds_bwd = std::max(h->top_lds_bwd, lb);
+          titems.push_back(T);
+        }
       }
       if ((rc = upload(h, h->d_top_sn, top))) return rc;
+      if ((rc = upload(h, h->d_titems, titems))) return rc;
     }
     HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)ns * sizeof(int), 16)));
   }
@@ -591,11 +630,11 @@ static void solve_m_async(hipfact_handle* h) {
   if (ltop < P.nlevels) {
     (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
     LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
-           h->d_top_sn.as<int>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
+           h->d_titems.as<TopItem>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
            h->d_y.as<double>(), h->d_uvec.as<double>(), h->d_flags.as<int>(), h->d_info.as<int>());
     (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
     LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
-           h->d_top_sn.as<int>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
+           h->d_titems.as<TopItem>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_flags.as<int>(), h->d_info.as<int>());
   }
   for (int l = ltop - 1; l >= 0; --l) {
@@ -839,6 +878,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_REFINE")) h->refine_steps = atoi(s);
   if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_PULL_MAX")) h->pull_max_children = atoi(s);
+  if (const char* s = getenv("HIPFACT_TOP_PREFETCH")) h->top_prefetch = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
@@ -1388,6 +1428,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "top_max_fronts")) {  // 0 disables the single-launch top-of-tree solve
     h->top_max_fronts = (int)value;
+    drop_graphs(h);
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "top_prefetch")) {
+    h->top_prefetch = value != 0.0;
     drop_graphs(h);
     h->have_plan = false;
     h->factored = false;

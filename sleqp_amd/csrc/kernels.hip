@@ -39,10 +39,31 @@ __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __re
                                                    const IDX* __restrict__ target, const double* __restrict__ Kval,
                                                    double* __restrict__ L) {
   for (long long e = blockIdx.x * (long long)FB + threadIdx.x; e < nM; e += (long long)gridDim.x * FB) {
+    const long long p0 = (long long)prod_ptr[e], p1 = (long long)prod_ptr[e + 1];
+    const long long tgt = (long long)target[e];
     double s = 0.0;
-    const long long p1 = (long long)prod_ptr[e + 1];
-    for (long long p = (long long)prod_ptr[e]; p < p1; ++p) s += Kval[prod_a[p]] * Kval[prod_b[p]];
-    L[(long long)target[e]] = s;
+    if (p1 > p0) {
+      // the first four products (most entries have at most two) as one batch of independent
+      // loads, clamped to the last valid one; the sum keeps the order of the list
+      int a[4], b[4];
+      double x[4], y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long p = (p0 + q < p1) ? p0 + q : p1 - 1;
+        a[q] = prod_a[p];
+        b[q] = prod_b[p];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        x[q] = Kval[a[q]];
+        y[q] = Kval[b[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (p0 + q < p1) s = fma(x[q], y[q], s);
+      for (long long p = p0 + 4; p < p1; ++p) s = fma(Kval[prod_a[p]], Kval[prod_b[p]], s);
+    }
+    L[tgt] = s;
   }
 }
 template __global__ void k_mvals_prod<long long>(long long, const long long*, const int*, const int*,
@@ -978,6 +999,147 @@ __device__ __forceinline__ void dev_fwd_front(const SnDesc& S, const SnDesc* __r
 }
 
 
+__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info);
+
+// Forward step of one front inside the single-launch top-of-tree kernel.  Everything that does
+// not depend on the children is requested BEFORE the wait for their flags: own right-hand side,
+// the children's relative indices (LDS), this thread's fragments of inv(L11) (registers) and L21
+// (LDS).  After the wait only the children's update vectors are one memory round trip away.
+// Same arithmetic, in the same order, as dev_fwd_front.
+__device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double* __restrict__ L,
+                                                  const int* __restrict__ rel, double* __restrict__ y,
+                                                  double* __restrict__ uvec, double* lds, int* __restrict__ flags,
+                                                  int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = T.w, r = T.r, u = r - w;
+  const double* __restrict__ P = L + T.Loff;
+  double* f = lds;            // r
+  double* xs = f + r;         // w
+  double* ps = xs + w;        // 8 x w partial sums of the triangular product
+  double* part = ps + 8 * w;  // <= 1024 partial sums of the rectangular product
+  int* relc = reinterpret_cast<int*>(part + 1024);  // TOP_REL_CAP ints
+  double* Lb = part + 1024 + TOP_REL_CAP / 2;       // u x w, column-major
+  for (int t = tid; t < r; t += SB) f[t] = (t < w) ? y[T.c0 + t] : 0.0;
+  {
+    int off = 0;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < T.nchild) {
+        const int* __restrict__ rc = rel + T.c_reloff[ch];
+        for (int a = tid; a < T.c_uc[ch]; a += SB) relc[off + a] = rc[a];
+        off += T.c_uc[ch];
+      }
+  }
+  // row k of inv(L11), eighth p of the column range [0, k): at most 16 entries
+  const int xk = tid & 127, xp = tid >> 7;
+  const int xlo = (int)(((long long)xk * xp) >> 3), xhi = (int)(((long long)xk * (xp + 1)) >> 3);
+  double xr[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xr[j] = (xk < w && xlo + j < xhi) ? P[xk + (long long)(xlo + j) * r] : 0.0;
+  for (int k0 = 4 * wave; k0 < w; k0 += 64)
+    for (int a = lane; a < u; a += 64) {
+      double v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (k0 + c < w) ? P[w + a + (long long)(k0 + c) * r] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (k0 + c < w) Lb[a + (k0 + c) * u] = v[c];
+    }
+  // ---- dependency wait
+  bool waited = false;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < T.nchild && T.c_wait[ch]) {
+      top_wait(flags, T.c_id[ch], info);
+      waited = true;
+    }
+  if (!waited) __syncthreads();
+  {
+    int off = 0;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < T.nchild) {
+        const double* __restrict__ uv = uvec + T.c_uoff[ch];
+        for (int a = tid; a < T.c_uc[ch]; a += SB) f[relc[off + a]] += uv[a];
+        off += T.c_uc[ch];
+        __syncthreads();
+      }
+  }
+  if (xk < w) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int n = xhi - xlo, n4 = n & ~3;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4)
+      if (j < n4) {
+        s0 += xr[j] * f[xlo + j];
+        s1 += xr[j + 1] * f[xlo + j + 1];
+        s2 += xr[j + 2] * f[xlo + j + 2];
+        s3 += xr[j + 3] * f[xlo + j + 3];
+      }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j >= n4 && j < n) s0 += xr[j] * f[xlo + j];
+    ps[xp * w + xk] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int k = tid; k < w; k += SB) {
+    double s = f[k];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s += ps[p * w + k];
+    xs[k] = s;
+    y[T.c0 + k] = s;
+  }
+  __syncthreads();
+  if (u > 0) {
+    const int nchunk = (u + 63) >> 6;
+    const int nslice = nchunk >= 16 ? 1 : 16 / nchunk;  // u * w <= TOP_L21_CAP: nchunk < 16 unless w < 17
+    double* __restrict__ us = uvec + T.uoff;
+    if (nslice == 1) {
+      for (int ch = wave; ch < nchunk; ch += 16) {
+        const int a = (ch << 6) + lane;
+        if (a < u) {
+          const double* Lr = Lb + a;
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+          int k = 0;
+          for (; k + 3 < w; k += 4) {
+            s0 += Lr[k * u] * xs[k];
+            s1 += Lr[(k + 1) * u] * xs[k + 1];
+            s2 += Lr[(k + 2) * u] * xs[k + 2];
+            s3 += Lr[(k + 3) * u] * xs[k + 3];
+          }
+          for (; k < w; ++k) s0 += Lr[k * u] * xs[k];
+          us[a] = f[w + a] - ((s0 + s1) + (s2 + s3));
+        }
+      }
+    } else {
+      const int ch = wave % nchunk, sl = wave / nchunk;
+      if (sl < nslice) {
+        const int a = (ch << 6) + lane;
+        const int lo = (int)(((long long)w * sl) / nslice), hi = (int)(((long long)w * (sl + 1)) / nslice);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (a < u) {
+          const double* Lr = Lb + a;
+          int k = lo;
+          for (; k + 3 < hi; k += 4) {
+            s0 += Lr[k * u] * xs[k];
+            s1 += Lr[(k + 1) * u] * xs[k + 1];
+            s2 += Lr[(k + 2) * u] * xs[k + 2];
+            s3 += Lr[(k + 3) * u] * xs[k + 3];
+          }
+          for (; k < hi; ++k) s0 += Lr[k * u] * xs[k];
+        }
+        part[sl * (nchunk << 6) + (ch << 6) + lane] = (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+      for (int a = tid; a < u; a += SB) {
+        double s = 0.0;
+        for (int sl2 = 0; sl2 < nslice; ++sl2) s += part[sl2 * (nchunk << 6) + a];
+        us[a] = f[w + a] - s;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rel,
                                                   const int* __restrict__ child_idx, double* __restrict__ y,
@@ -987,7 +1149,6 @@ __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn,
   dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
 }
 
-__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info);
 
 // backward step of one front (lds: u + w doubles).  In the single-launch top-of-tree
 // kernel (flags != nullptr) the wait for the parent happens AFTER the panel
@@ -1147,32 +1308,145 @@ __device__ __forceinline__ void top_publish(int* __restrict__ flags, int who) {
   }
 }
 
-// top_sn: fronts of the levels >= top_level; S.pad0 holds the level of a front
-__global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, const int* __restrict__ top_sn,
+// titems: fronts of the levels >= top_level, children before parents
+__global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, const TopItem* __restrict__ titems,
                                                 int top_level, const double* __restrict__ L,
                                                 const int* __restrict__ rel, const int* __restrict__ child_idx,
                                                 double* __restrict__ y, double* __restrict__ uvec,
                                                 int* __restrict__ flags, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int s = top_sn[blockIdx.x];
-  const SnDesc S = sn[s];
-  for (int ci = S.child_begin; ci < S.child_end; ++ci) {
-    const int c = child_idx[ci];
-    if (sn[c].pad0 >= top_level) top_wait(flags, c, info);
+  const TopItem& T = titems[blockIdx.x];
+  if (T.prefetch & 1) {
+    dev_fwd_front_top(T, L, rel, y, uvec, lds, flags, info);
+  } else {
+    const SnDesc S = sn[T.s];
+    for (int ci = S.child_begin; ci < S.child_end; ++ci) {
+      const int c = child_idx[ci];
+      if (sn[c].pad0 >= top_level) top_wait(flags, c, info);
+    }
+    dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
   }
-  dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
-  top_publish(flags, s);
+  top_publish(flags, T.s);
 }
 
-__global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, const int* __restrict__ top_sn,
+// Backward step of one front inside the single-launch top-of-tree kernel: the L21 fragments
+// (registers), inv(L11), the pivots, the own part of the solution and the row list (LDS) are
+// requested BEFORE the wait for the parent; afterwards only the ancestors' solution entries
+// are one memory round trip away.  Same arithmetic, in the same order, as dev_bwd_front.
+__device__ __forceinline__ void dev_bwd_front_top(const TopItem& T, const double* __restrict__ L,
+                                                  const int* __restrict__ rows, double* __restrict__ y, double* lds,
+                                                  int* __restrict__ flags, int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = T.w, r = T.r, u = r - w;  // u <= 256
+  const double* __restrict__ P = L + T.Loff;
+  const int* __restrict__ rw = rows + T.rowoff + w;
+  double* g = lds;         // u
+  double* v = g + u;       // w
+  double* dpre = v + w;    // w pivots
+  double* ypre = dpre + w; // w own entries of the forward result
+  int* rwb = reinterpret_cast<int*>(ypre + w);  // u
+  double* Xb = ypre + w + ((u + 1) >> 1);       // w x w, strict lower part used
+  double lv[2][4][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * (wave + 16 * p) + c;
+      const double* col = P + (long long)k * r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = lane + 64 * q;
+        lv[p][c][q] = (k < w && a < u) ? col[w + a] : 0.0;
+      }
+    }
+  for (int a = tid; a < u; a += SB) rwb[a] = rw[a];
+  for (int k = tid; k < w; k += SB) {
+    dpre[k] = P[k + (long long)k * r];
+    ypre[k] = y[T.c0 + k];
+  }
+  for (int k0 = 4 * wave; k0 < w; k0 += 64)
+    for (int t = lane; t < w; t += 64) {
+      double x[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x[c] = (k0 + c < w && t > k0 + c) ? P[t + (long long)(k0 + c) * r] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (k0 + c < w) Xb[t + (k0 + c) * w] = x[c];
+    }
+  if (T.parent >= 0)
+    top_wait(flags, T.parent, info);  // the parent is done only after all its ancestors
+  else
+    __syncthreads();
+  for (int a = tid; a < u; a += SB) g[a] = y[rwb[a]];
+  __syncthreads();
+  // v_k = z_k / d_k - L21(:,k)^T g
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (4 * (wave + 16 * p) >= w) continue;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = lane + 64 * q;
+        if (a < u) s[c] += lv[p][c][q] * g[a];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * (wave + 16 * p) + c;
+        if (k < w) v[k] = ypre[k] / dpre[k] - s[c];
+      }
+    }
+  }
+  __syncthreads();
+  // x_k = v_k + inv(L11)(:,k)^T v below the diagonal
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (4 * (wave + 16 * p) >= w) continue;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * (wave + 16 * p) + c;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = k + 1 + lane + 64 * q;
+        if (k < w && t < w) s[c] += Xb[t + k * w] * v[t];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * (wave + 16 * p) + c;
+        if (k < w) y[T.c0 + k] = v[k] + s[c];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, const TopItem* __restrict__ titems,
                                                 const double* __restrict__ L, const int* __restrict__ rows,
                                                 double* __restrict__ y, int* __restrict__ flags,
                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int s = top_sn[blockIdx.x];
-  const SnDesc S = sn[s];
-  dev_bwd_front(S, L, rows, y, lds, flags, info);
-  top_publish(flags, s);
+  const TopItem& T = titems[blockIdx.x];
+  if (T.prefetch & 2) {
+    dev_bwd_front_top(T, L, rows, y, lds, flags, info);
+  } else {
+    const SnDesc S = sn[T.s];
+    dev_bwd_front(S, L, rows, y, lds, flags, info);
+  }
+  top_publish(flags, T.s);
 }
 
 // ---------------------------------------------------------------------------

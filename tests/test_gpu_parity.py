@@ -335,6 +335,28 @@ def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
 
+def test_top_of_tree_solve_variants_agree_bitwise(fact):
+    """Level-by-level solve launches, the single-launch top-of-tree kernels, and their
+    panel-prefetching variant run the same arithmetic in the same order: identical bits."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 12)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    b = np.random.default_rng(2).standard_normal(N)
+    fact.set_option("refine_steps", 0)
+    outs = []
+    for top_max, prefetch in ((0, 0), (192, 0), (192, 1)):
+        fact.set_option("top_max_fronts", top_max)
+        fact.set_option("top_prefetch", prefetch)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+        assert (fact.info("top_level") < fact.info("nlevels")) == (top_max > 0)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    assert scaled_residual(K, outs[0], b) <= 1e-9
+
+
 @pytest.mark.parametrize("workload", ["banded_n1e5_m5e4", "uniform_n1e4_m5e3"])
 def test_full_size_properties(fact, workload):
     """BASELINE.json configs[3] / configs[2] at full size: properties that do not need the dense oracle."""
