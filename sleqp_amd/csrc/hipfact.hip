@@ -136,7 +136,7 @@ struct hipfact_handle {
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
   // top of the tree solved in one launch per direction (levels >= top_level)
-  int top_level = 1 << 30, top_count = 0, top_max_fronts = 192;
+  int top_level = 1 << 30, top_count = 0, top_max_fronts = 256;
   size_t top_lds_fwd = 0, top_lds_bwd = 0;
   Prof prof;
   // plan on device
@@ -359,7 +359,11 @@ static int upload_plan(hipfact_handle* h) {
     li.lds_schur = (wp + needD) * sizeof(double);
     li.lds_asm = ((size_t)P.max_u + 16) * sizeof(int);
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
-    li.lds_bwd = ((size_t)mu + mw + 2) * sizeof(double);
+    {
+      // dev_bwd_front: u + w; dev_bwd_small (u <= 256): 4 ceil(u/4) + (wp + 4) + wp + 256 + ceil(u/2)
+      const size_t us = (size_t)std::min(mu, 256);
+      li.lds_bwd = std::max((size_t)mu + mw + 2, us + 4 + 2 * wp + 4 + 256 + us / 2 + 2) * sizeof(double);
+    }
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
     // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
     li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5);
@@ -471,7 +475,7 @@ static int upload_plan(hipfact_handle* h) {
           T.parent = sn[s].parent;
           const int nch = sn[s].child_end - sn[s].child_begin;
           const long long u = T.r - T.w;
-          long long sum_uc = 0;
+          long long sum_uc = 0, max_uc = 0;
           T.nchild = nch <= MAXCH ? nch : -1;
           for (int k = 0; k < nch && nch <= MAXCH; ++k) {
             const int ch = P.child_idx[sn[s].child_begin + k];
@@ -481,15 +485,17 @@ static int upload_plan(hipfact_handle* h) {
             T.c_id[k] = ch;
             T.c_wait[k] = P.sn_level[ch] >= lvl;
             sum_uc += T.c_uc[k];
+            max_uc = std::max<long long>(max_uc, T.c_uc[k]);
           }
           size_t lf = h->levels[l].lds_fwd, lb = h->levels[l].lds_bwd;
-          if (h->top_prefetch && T.nchild >= 0 && sum_uc <= TOP_REL_CAP && u * T.w <= TOP_L21_CAP) {
+          if (h->top_prefetch && T.nchild >= 0 && sum_uc <= TOP_REL_CAP && max_uc <= SB && u * T.w <= TOP_L21_CAP) {
             T.prefetch |= 1;
             lf = ((size_t)T.r + 9 * (size_t)T.w + 1024 + TOP_REL_CAP / 2 + (size_t)(u * T.w) + 2) * sizeof(double);
           }
-          if (h->top_prefetch && u <= 256) {
+          if (u <= 256) {  // same arithmetic as the level kernels' small-front path
             T.prefetch |= 2;
-            lb = ((size_t)u + 3 * (size_t)T.w + (size_t)((u + 1) / 2) + (size_t)T.w * T.w + 2) * sizeof(double);
+            const size_t wp16 = (size_t)((T.w + 15) & ~15);
+            lb = ((size_t)u + 4 + 2 * wp16 + 4 + 256 + (size_t)((u + 1) / 2) + (size_t)T.w * T.w + 2) * sizeof(double);
           }
           h->top_lds_fwd = std::max(h->top_lds_fwd, lf);
           h->top_lds_bwd = std::max(h->top_lds_bwd, lb);

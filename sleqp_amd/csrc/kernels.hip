@@ -1055,12 +1055,15 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
     }
   if (!waited) __syncthreads();
   {
+    // all children's update vectors leave together (uc <= SB each); they are added child by child
+    double uvv[MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) uvv[ch] = (ch < T.nchild && tid < T.c_uc[ch]) ? uvec[T.c_uoff[ch] + tid] : 0.0;
     int off = 0;
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < T.nchild) {
-        const double* __restrict__ uv = uvec + T.c_uoff[ch];
-        for (int a = tid; a < T.c_uc[ch]; a += SB) f[relc[off + a]] += uv[a];
+        if (tid < T.c_uc[ch]) f[relc[off + tid]] += uvv[ch];
         off += T.c_uc[ch];
         __syncthreads();
       }
@@ -1261,12 +1264,135 @@ __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __r
 }
 
 
+// Backward step of a front with u <= 256 update rows, both products on the matrix cores: a GEMV
+// as an MFMA whose B operand repeats the vector in all 16 columns wastes 15/16 of the flops,
+// but it needs no cross-lane reduction at all (a wave-level shuffle tree costs ~500 VALU
+// instructions per wave, and with 16 waves per CU that is microseconds on the critical path).
+//   v = z / d - L21^T g      wave (kb, sp): 16 pivot columns x one slice of the update rows
+//   x = v + strict_lower(inv(L11))^T v
+// Slices are added in a fixed order through LDS.  TOP: part of the single-launch top-of-tree
+// kernel; everything that does not depend on the ancestors (L21 fragments in registers,
+// inv(L11), z / d and the row list in LDS) is requested BEFORE the wait for the parent.
+// lds (doubles): 4 ceil(u/4) | wp + 4 | wp | 256 | ceil(u/2) | TOP: w w
+template <bool TOP>
+__device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, int c0, int w, int r, int parent,
+                                              const double* __restrict__ L, const int* __restrict__ rows,
+                                              double* __restrict__ y, double* lds, int* __restrict__ flags,
+                                              int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int u = r - w;
+  const int nbk = (w + 15) >> 4, wp = nbk << 4;
+  const int nsplit = 16 / nbk;  // >= 2
+  const int kb = wave % nbk, sp = wave / nbk;
+  const bool active = sp < nsplit;
+  const int nac = (u + 3) >> 2;  // chunks of 4 update rows, <= 64
+  const int c_lo = nac * sp / nsplit, c_hi = nac * (sp + 1) / nsplit;
+  const int k = 16 * kb + li;
+  const double* __restrict__ P = L + Loff;
+  const int* __restrict__ rw = rows + rowoff + w;
+  double* g = lds;                // 4 nac
+  double* v = g + 4 * nac;        // wp + 4 (zero beyond w)
+  double* ypre = v + wp + 4;      // z_k / d_k
+  double* part = ypre + wp;       // nsplit x wp <= 256 partial sums
+  int* rwb = reinterpret_cast<int*>(part + 256);
+  double* Xb = part + 256 + ((u + 1) >> 1);  // TOP: w x w, zero on and above the diagonal
+  for (int a = tid; a < 4 * nac; a += SB) {
+    if (a < u)
+      rwb[a] = rw[a];
+    else
+      g[a] = 0.0;
+  }
+  for (int t = tid; t < wp + 4; t += SB) {
+    if (t < w)
+      ypre[t] = y[c0 + t] / P[t + (long long)t * r];
+    else
+      v[t] = 0.0;
+  }
+  if (TOP) {
+    for (int k0 = 4 * wave; k0 < w; k0 += 64)
+      for (int t = lane; t < w; t += 64) {
+        double x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = (k0 + c < w && t > k0 + c) ? P[t + (long long)(k0 + c) * r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (k0 + c < w) Xb[t + (k0 + c) * w] = x[c];
+      }
+  }
+  // (requested last: the staging loops above then run without these 64 registers live)
+  double lv[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int a = 4 * (c_lo + j) + lk;
+    lv[j] = (active && c_lo + j < c_hi && k < w && a < u) ? P[w + a + (long long)k * r] : 0.0;
+  }
+  if (TOP && parent >= 0)
+    top_wait(flags, parent, info);  // the parent is done only after all its ancestors
+  else
+    __syncthreads();
+  for (int a = tid; a < u; a += SB) g[a] = y[rwb[a]];
+  __syncthreads();
+  if (active) {
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (c_lo + j < c_hi) acc = MFMA_F64(lv[j], g[4 * (c_lo + j) + lk], acc);
+    if (li == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[sp * wp + 16 * kb + lk + 4 * q] = acc[q];
+    }
+  }
+  // strict lower part of inv(L11)^T: chunks of 4 rows t below the first column of the block
+  const int ntc = (w + 3) >> 2;
+  const int cnt = ntc - 4 * kb;
+  const int t_lo = 4 * kb + cnt * sp / nsplit, t_hi = 4 * kb + cnt * (sp + 1) / nsplit;
+  double xf[16];
+  if (!TOP) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = 4 * (t_lo + j) + lk;
+      xf[j] = (active && t_lo + j < t_hi && k < w && t < w && t > k) ? P[t + (long long)k * r] : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < w; t += SB) {
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += part[q * wp + t];
+    v[t] = ypre[t] - s;
+  }
+  __syncthreads();
+  if (active) {
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (t_lo + j < t_hi) {
+        const int t = 4 * (t_lo + j) + lk;
+        const double xa = TOP ? ((k < w && t < w) ? Xb[t + k * w] : 0.0) : xf[j];
+        acc = MFMA_F64(xa, v[t], acc);
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[sp * wp + 16 * kb + lk + 4 * q] = acc[q];
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < w; t += SB) {
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += part[q * wp + t];
+    y[c0 + t] = v[t] + s;
+  }
+}
+
 __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rows,
                                                   double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const SnDesc S = sn[level_sn[blockIdx.x]];
-  dev_bwd_front(S, L, rows, y, lds);
+  if (S.r - S.w <= 256)
+    dev_bwd_small<false>(S.Loff, S.rowoff, S.c0, S.w, S.r, S.parent, L, rows, y, lds, nullptr, nullptr);
+  else
+    dev_bwd_front(S, L, rows, y, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1329,119 +1455,16 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
   top_publish(flags, T.s);
 }
 
-// Backward step of one front inside the single-launch top-of-tree kernel: the L21 fragments
-// (registers), inv(L11), the pivots, the own part of the solution and the row list (LDS) are
-// requested BEFORE the wait for the parent; afterwards only the ancestors' solution entries
-// are one memory round trip away.  Same arithmetic, in the same order, as dev_bwd_front.
-__device__ __forceinline__ void dev_bwd_front_top(const TopItem& T, const double* __restrict__ L,
-                                                  const int* __restrict__ rows, double* __restrict__ y, double* lds,
-                                                  int* __restrict__ flags, int* __restrict__ info) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int w = T.w, r = T.r, u = r - w;  // u <= 256
-  const double* __restrict__ P = L + T.Loff;
-  const int* __restrict__ rw = rows + T.rowoff + w;
-  double* g = lds;         // u
-  double* v = g + u;       // w
-  double* dpre = v + w;    // w pivots
-  double* ypre = dpre + w; // w own entries of the forward result
-  int* rwb = reinterpret_cast<int*>(ypre + w);  // u
-  double* Xb = ypre + w + ((u + 1) >> 1);       // w x w, strict lower part used
-  double lv[2][4][4];
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = 4 * (wave + 16 * p) + c;
-      const double* col = P + (long long)k * r;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = lane + 64 * q;
-        lv[p][c][q] = (k < w && a < u) ? col[w + a] : 0.0;
-      }
-    }
-  for (int a = tid; a < u; a += SB) rwb[a] = rw[a];
-  for (int k = tid; k < w; k += SB) {
-    dpre[k] = P[k + (long long)k * r];
-    ypre[k] = y[T.c0 + k];
-  }
-  for (int k0 = 4 * wave; k0 < w; k0 += 64)
-    for (int t = lane; t < w; t += 64) {
-      double x[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) x[c] = (k0 + c < w && t > k0 + c) ? P[t + (long long)(k0 + c) * r] : 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (k0 + c < w) Xb[t + (k0 + c) * w] = x[c];
-    }
-  if (T.parent >= 0)
-    top_wait(flags, T.parent, info);  // the parent is done only after all its ancestors
-  else
-    __syncthreads();
-  for (int a = tid; a < u; a += SB) g[a] = y[rwb[a]];
-  __syncthreads();
-  // v_k = z_k / d_k - L21(:,k)^T g
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    if (4 * (wave + 16 * p) >= w) continue;
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = lane + 64 * q;
-        if (a < u) s[c] += lv[p][c][q] * g[a];
-      }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 4 * (wave + 16 * p) + c;
-        if (k < w) v[k] = ypre[k] / dpre[k] - s[c];
-      }
-    }
-  }
-  __syncthreads();
-  // x_k = v_k + inv(L11)(:,k)^T v below the diagonal
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    if (4 * (wave + 16 * p) >= w) continue;
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = 4 * (wave + 16 * p) + c;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int t = k + 1 + lane + 64 * q;
-        if (k < w && t < w) s[c] += Xb[t + k * w] * v[t];
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s[c] += __shfl_down(s[c], o, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 4 * (wave + 16 * p) + c;
-        if (k < w) y[T.c0 + k] = v[k] + s[c];
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, const TopItem* __restrict__ titems,
                                                 const double* __restrict__ L, const int* __restrict__ rows,
                                                 double* __restrict__ y, int* __restrict__ flags,
                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const TopItem& T = titems[blockIdx.x];
+  // parents before children: workgroups are dispatched in index order, so a front never waits
+  // for one that has not been dispatched yet (no co-residency assumption for correctness)
+  const TopItem& T = titems[gridDim.x - 1 - blockIdx.x];
   if (T.prefetch & 2) {
-    dev_bwd_front_top(T, L, rows, y, lds, flags, info);
+    dev_bwd_small<true>(T.Loff, T.rowoff, T.c0, T.w, T.r, T.parent, L, rows, y, lds, flags, info);
   } else {
     const SnDesc S = sn[T.s];
     dev_bwd_front(S, L, rows, y, lds, flags, info);
