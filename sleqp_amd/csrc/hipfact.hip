@@ -356,7 +356,7 @@ static int upload_plan(hipfact_handle* h) {
     li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
     li.lds_pivot = (wp + needB) * sizeof(double) + MAXCH * wp * sizeof(int);
     li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double) + MAXCH * wp * sizeof(int);
-    li.lds_schur = (wp + needD) * sizeof(double);
+    li.lds_schur = (wp + needD) * sizeof(double) + 128 * MAXCH * sizeof(int);
     li.lds_asm = ((size_t)P.max_u + 16) * sizeof(int);
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
     {

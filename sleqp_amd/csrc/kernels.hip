@@ -693,48 +693,20 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
         uv[x][y][q] = (!assign && !idle && pc.n == 0 && i < u && j < u && i >= j) ? c.Us[i + (long long)j * u] : 0.0;
       }
     }
-  if (!idle && pc.n > 0) {
-    int ci[MAXCH][2], cj[MAXCH][2][4];
+  // pull mode: the children's inverse maps of the tile's 64 rows and 64 columns go through LDS
+  // (two entries per thread); the gathers themselves run after the MFMA work, so that the operand
+  // staging is not delayed by their two dependent round trips
+  int* invs = reinterpret_cast<int*>(SJ + 64 * KC);  // [child][0..63: rows | 64..127: columns]
+  int ivr[2] = {-1, -1};
+  if (pc.n > 0) {
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
+    for (int h = 0; h < 2; ++h) {
+      const int ch = (tid >> 7) + 2 * h, idx = tid & 127;
+      const int gi = (idx < 64) ? 64 * I + idx : 64 * J + idx - 64;
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        const int i = 64 * I + i0 + 16 * y + li;
-        ci[ch][y] = (ch < pc.n && i < u) ? pc.inv[ch][w + i] : -1;
-      }
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = 64 * J + j0 + 16 * x + lk + 4 * q;
-          cj[ch][x][q] = (ch < pc.n && j < u) ? pc.inv[ch][w + j] : -1;
-        }
+      for (int cc = 0; cc < MAXCH; ++cc)
+        if (cc == ch && cc < pc.n && gi < u) ivr[h] = pc.inv[cc][w + gi];
     }
-#pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < pc.n) {
-        const double* __restrict__ Uc = pc.Uc[ch];
-        const int uc = pc.uc[ch];
-        double g[2][2][4];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              // rel is monotone: i >= j in the front implies ci >= cj in the child; loads are
-              // unconditional (clamped to entry 0) so that they all leave in one batch
-              const bool ok = ci[ch][y] >= 0 && cj[ch][x][q] >= 0 && ci[ch][y] >= cj[ch][x][q];
-              const double gv = Uc[ok ? ci[ch][y] + (long long)cj[ch][x][q] * uc : 0];
-              g[x][y][q] = ok ? gv : 0.0;
-            }
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) uv[x][y][q] += g[x][y][q];
-      }
   }
   const int si = tid & 63;
   const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
@@ -762,6 +734,10 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
         }
       }
     }
+    if (kc0 == 0 && pc.n > 0) {
+      invs[tid] = ivr[0];
+      invs[tid + 256] = ivr[1];
+    }
     __syncthreads();
     if (!idle) {
       const int k4 = kcn & ~3;
@@ -787,6 +763,39 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     }
   }
   if (idle) return;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n) {
+      const double* __restrict__ Uc = pc.Uc[ch];
+      const int uc = pc.uc[ch];
+      const int* iv = invs + 128 * ch;
+      int ci[2], cj[2][4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) ci[y] = iv[i0 + 16 * y + li];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cj[x][q] = iv[64 + j0 + 16 * x + lk + 4 * q];
+      double g[2][2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // rel is monotone: i >= j in the front implies ci >= cj in the child; loads are
+            // unconditional (clamped to entry 0) so that they all leave in one batch
+            const bool ok = ci[y] >= 0 && cj[x][q] >= 0 && ci[y] >= cj[x][q];
+            const double gv = Uc[ok ? ci[y] + (long long)cj[x][q] * uc : 0];
+            g[x][y][q] = ok ? gv : 0.0;
+          }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) uv[x][y][q] += g[x][y][q];
+    }
   // acc[x][y][q] = update of U(i = 64 I + i0 + 16 y + li, j = 64 J + j0 + 16 x + lk + 4 q)
 #pragma unroll
   for (int x = 0; x < 2; ++x)
