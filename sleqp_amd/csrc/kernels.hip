@@ -333,6 +333,9 @@ __device__ __forceinline__ void dev_trailing_tile(const FrontCtx& c, int k0, int
 // Blocked right-looking LDL^T (nb = 16) with look-ahead: in the trailing update of
 // step kb, wave 0 updates the next diagonal tile first and factors it at once,
 // while the other waves finish the remaining tiles.  Any number of waves >= 1.
+// ROWINV (8 waves): the inverse of the unit lower factor is formed block row by block row in
+// the shadow of the diagonal-block chain instead of by recursive doubling afterwards.
+template <bool ROWINV>
 __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
@@ -416,8 +419,19 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
   __syncthreads();
 
+  // ROWINV: block row kb of X = inv(L): X[kb, j] = -X_kk sum_{i=j}^{kb-1} L[kb, i] X[i, j], one tile
+  // j per wave (waves 1..7), computed during step kb (X_kk is final, wave 0 is busy with the
+  // next diagonal block) and written over L[kb, j] at the start of the next step, when nobody
+  // reads block row kb of L any more.
+  d4_t xpend = {0.0, 0.0, 0.0, 0.0};
+  int xrow = -1, xcol = -1;
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb << 4;
+    if (ROWINV && xrow >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A[(16 * xrow + lk + 4 * q) + (16 * xcol + li) * lda] = -xpend[q];
+      xrow = -1;
+    }
     // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
     if (!(phases & 64))
       for (int I = kb + 1 + wave; I < nbk; I += nw) {
@@ -460,15 +474,37 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
           }
       }
     }
+    if (ROWINV && wave >= 1 && wave - 1 < kb && !(phases & 128)) {
+      const int j = wave - 1;
+      d4_t t = {0.0, 0.0, 0.0, 0.0};
+      for (int i = j; i < kb; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const double av = A[(k0 + li) + (16 * i + 4 * s2 + lk) * lda];      // L[kb, i]
+          const double bv = A[(16 * i + 4 * s2 + lk) + (16 * j + li) * lda];  // X[i, j] (X_jj for i = j)
+          t = MFMA_F64(av, bv, t);
+        }
+      d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) x = MFMA_F64(A[(k0 + li) + (k0 + 4 * s2 + lk) * lda], t[s2], x);  // X_kk T
+      xpend = x;
+      xrow = kb;
+      xcol = j;
+    }
     __syncthreads();
   }
+  if (ROWINV && xrow >= 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[(16 * xrow + lk + 4 * q) + (16 * xcol + li) * lda] = -xpend[q];
+  }
+  if (ROWINV) __syncthreads();
 
   // inverse of the unit lower block factor by recursive doubling.  A holds
   // inv(L_kk) in the diagonal blocks and L_IJ below.  For [X11 0; B X22] the
   // off-diagonal block of the inverse is -X22 B X11; one wave computes one
   // 16-column strip of it in registers (the accumulator tiles of the first
   // product are the B operands of the second), then all strips are stored.
-  for (int h = 16; h < wp && !(phases & 128); h <<= 1) {
+  for (int h = 16; h < wp && !(phases & 128) && !ROWINV; h <<= 1) {
     const int ht = h >> 4;
     const int ntask = (wp + 2 * h - 1) / (2 * h);
     const int units = ntask * ht;
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
   if (!(phases & 2)) return;
   PullCtx nopull;
   nopull.n = 0;
-  dev_pivot_block(c, info, phases, nopull);
+  dev_pivot_block<false>(c, info, phases, nopull);
   dev_store_pivot_block(c);
   if (!(phases & 4)) return;
   dev_panel_solve<true>(c, 0, 1, nopull, nullptr);
@@ -860,7 +896,7 @@ __global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
-  dev_pivot_block(c, info, 15, pc);
+  dev_pivot_block<true>(c, info, 15, pc);
   dev_store_pivot_block(c);
 }
 
