@@ -429,7 +429,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     const int k0 = kb << 4;
     if (ROWINV && xrow >= 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) A[(16 * xrow + lk + 4 * q) + (16 * xcol + li) * lda] = -xpend[q];
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * xrow + lk + 4 * q, col = 16 * xcol + li;
+        A[row + col * lda] = -xpend[q];
+        if (row < w) c.P[row + (long long)col * r] = -xpend[q];  // final: straight to the panel as well
+      }
       xrow = -1;
     }
     // S2: block column.  Y_Ik = A_Ik X_kk^T, L_Ik = Y_Ik D^-1.
@@ -474,6 +478,14 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
           }
       }
     }
+    if (ROWINV && wave == 1 + (kb + 3) % 7) {
+      // diagonal block kb is final since S1(kb): inverse of its unit factor below, pivots on the diagonal
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = k0 + li, col = k0 + lk + 4 * q;
+        if (row < w && col <= row) c.P[row + (long long)col * r] = (row == col) ? dd[col] : A[row + col * lda];
+      }
+    }
     if (ROWINV && wave >= 1 && wave - 1 < kb && !(phases & 128)) {
       const int j = wave - 1;
       d4_t t = {0.0, 0.0, 0.0, 0.0};
@@ -495,7 +507,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   }
   if (ROWINV && xrow >= 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) A[(16 * xrow + lk + 4 * q) + (16 * xcol + li) * lda] = -xpend[q];
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * xrow + lk + 4 * q, col = 16 * xcol + li;
+      A[row + col * lda] = -xpend[q];
+      if (row < w) c.P[row + (long long)col * r] = -xpend[q];
+    }
   }
   if (ROWINV) __syncthreads();
 
@@ -896,8 +912,7 @@ __global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
-  dev_pivot_block<true>(c, info, 15, pc);
-  dev_store_pivot_block(c);
+  dev_pivot_block<true>(c, info, 15, pc);  // stores the finished tiles itself
 }
 
 // LDS: dd | X | MAXCH x wp ints (the children's inverse maps of the pivot columns)
