@@ -347,23 +347,32 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   double* scratch = Yp + 16 * lda;  // 32 doubles for the diagonal-block micro-kernel
   const double* __restrict__ P = c.P;
   if (pc.n > 0) {
-    // pull-mode extend-add (8 waves, wp <= 128: the whole block is one batch of 2 x 16 entries
-    // per thread).  Order of issue = order of the dependent round trips: the children's inverse
-    // maps of the pivot rows and the panel entries leave together; the maps go through LDS;
-    // then all gathers leave together.  Children are added in child order on top of the
-    // original entry, as dev_assemble does.
+    // pull-mode extend-add (8 waves, wp <= 128).  Order of issue = order of the dependent round
+    // trips: the children's inverse maps of the pivot rows and the panel entries leave together;
+    // the maps go through LDS; then the gathers leave.  Two stages: block column 0 (all threads,
+    // 4 entries each) is completed first, so that wave 0 can factor the first diagonal block
+    // while waves 1..7 finish the other columns (2 x 16 entries per thread).  Children are added
+    // in child order on top of the original entry, as dev_assemble does.
     int* invb = reinterpret_cast<int*>(scratch + 32);
     int iv[MAXCH];
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < pc.n && tid < w) ? pc.inv[ch][tid] : -1;
-    double v[2][16];
+    const int i1 = tid & 127, kq1 = tid >> 7;  // stage 1: row i1, columns kq1 + 4 q
+    double v1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = kq1 + 4 * q;
+      v1[q] = (i1 == k) ? 1.0 : 0.0;
+      if (i1 < w && k < w) v1[q] = (i1 >= k) ? P[i1 + (long long)k * r] : 0.0;
+    }
+    double v[2][16];  // stage 2 (waves 1..7): rows lane + 64 t, columns 16 + (wave - 1) + 7 q
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int i = lane + 64 * t, k = wave + 8 * q;
+        const int i = lane + 64 * t, k = 15 + wave + 7 * q;
         v[t][q] = (i == k) ? 1.0 : 0.0;
-        if (i < w && k < w) v[t][q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
+        if (wave >= 1 && i < w && k < w) v[t][q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
       }
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
@@ -375,28 +384,53 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         const double* __restrict__ Uc = pc.Uc[ch];
         const int uc = pc.uc[ch];
         const int* ib = invb + ch * wp;
-        int ci[2];
+        const int ci = (i1 < wp) ? ib[i1] : -1;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int k = wave + 8 * q;
-          const int ck = (k < wp) ? ib[k] : -1;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
-            const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
-            v[t][q] += ok ? g : 0.0;
-          }
+        for (int q = 0; q < 4; ++q) {
+          const int ck = ib[kq1 + 4 * q];
+          const bool ok = ci >= 0 && ck >= 0 && ci >= ck;
+          const double g = Uc[ok ? ci + (long long)ck * uc : 0];
+          v1[q] += ok ? g : 0.0;
         }
       }
+    if (i1 < wp) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);
+    } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int i = lane + 64 * t, k = wave + 8 * q;
-        if (i < wp && k < wp) A[i + k * lda] = v[t][q];
-      }
+      for (int ch = 0; ch < MAXCH; ++ch)
+        if (ch < pc.n) {
+          const double* __restrict__ Uc = pc.Uc[ch];
+          const int uc = pc.uc[ch];
+          const int* ib = invb + ch * wp;
+          int ci[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int k = 15 + wave + 7 * q;
+            const int ck = (k < wp) ? ib[k] : -1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
+              const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
+              v[t][q] += ok ? g : 0.0;
+            }
+          }
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = lane + 64 * t, k = 15 + wave + 7 * q;
+          if (i < wp && k < wp) A[i + k * lda] = v[t][q];
+        }
+    }
+    __syncthreads();
   } else {
     // eight columns per batch so that the panel loads are in flight together
     for (int kk = wave; kk < wp; kk += 8 * nw)
@@ -414,10 +448,10 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
           if (k < wp) A[i + k * lda] = v[q];
         }
       }
+    __syncthreads();
+    if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
-  __syncthreads();
 
   // ROWINV: block row kb of X = inv(L): X[kb, j] = -X_kk sum_{i=j}^{kb-1} L[kb, i] X[i, j], one tile
   // j per wave (waves 1..7), computed during step kb (X_kk is final, wave 0 is busy with the
