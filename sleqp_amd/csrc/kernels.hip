@@ -258,51 +258,57 @@ __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratc
   const int li = lane & 15, lk = lane >> 4;
   const int lda = c.lda;
   double* A = c.A;
-  double* colk = scratch;       // 16: A[.][k]
+  double* colk = scratch;       // 16: A[.][k] below the diagonal, 0 on and above it
   double* xrow = scratch + 16;  // 16: X[k][.]
   double a[4], x[4];
-  double dmine = 1.0;  // pivot of column li (kept by the lanes with lk == 0)
-  int nzero = 0, nneg = 0;
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) {
     a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
     x[cc] = (li == 4 * lk + cc) ? 1.0 : 0.0;
   }
+  // The dependent chain of the whole front runs through this loop (pivot -> reciprocal ->
+  // multiplier -> update of the next pivot), so nothing else sits on it: the exchanged column is
+  // zeroed on and above the diagonal when it is written (no selects on l_ik or on the update),
+  // and singular / negative pivots are counted after the loop from the diagonal, which is
+  // final once its row has been eliminated (a zero pivot then simply floods the block with
+  // non-finite values; the factorisation is reported singular either way).
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int qk = k >> 2, kr = k & 3;
-    if (lk == qk) colk[li] = a[kr];
+    if (lk == qk) colk[li] = (li > k) ? a[kr] : 0.0;
     if (li == k) {
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) xrow[4 * lk + cc] = x[cc];
     }
     __builtin_amdgcn_wave_barrier();
-    const double ck_i = colk[li];                   // A[i][k]
-    double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
-                                                    // reciprocal chain overlaps the LDS round trip
+    const double ck_i = colk[li];                         // A[i][k], i > k
+    const double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
+                                                          // reciprocal chain overlaps the LDS round trip
     double ckj[4], xk[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc
+      ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc (0 for j <= k)
       xk[cc] = xrow[4 * lk + cc];   // X[k][j]
     }
     __builtin_amdgcn_wave_barrier();
-    const bool bad = (d == 0.0) || !(fabs(d) <= 1.7e308);  // exactly singular or non-finite
-    nzero += bad ? 1 : 0;
-    d = bad ? 1.0 : d;
-    nneg += (d < 0.0) ? 1 : 0;
-    dmine = (li == k) ? d : dmine;
-    const double l_ik = (li > k) ? ck_i * fast_rcp(d) : 0.0;
+    const double l_ik = ck_i * fast_rcp(d);
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      const int j = 4 * lk + cc;
-      a[cc] = (j > k) ? fma(-l_ik, ckj[cc], a[cc]) : a[cc];
+      a[cc] = fma(-l_ik, ckj[cc], a[cc]);
       x[cc] = fma(-l_ik, xk[cc], x[cc]);
     }
   }
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
-  if (lk == 0) c.dd[k0 + li] = dmine;
+  // pivot of column li: the diagonal entry, held by the lane (li, lk = li / 4)
+  double dsel = a[0];
+#pragma unroll
+  for (int cc = 1; cc < 4; ++cc) dsel = ((li & 3) == cc) ? a[cc] : dsel;
+  const bool owner = (lk == (li >> 2));
+  const bool bad = owner && ((dsel == 0.0) || !(fabs(dsel) <= 1.7e308));  // exactly singular or non-finite
+  const bool neg = owner && !bad && (dsel < 0.0);
+  if (owner) c.dd[k0 + li] = bad ? 1.0 : dsel;
+  const int nzero = __popcll(__ballot(bad)), nneg = __popcll(__ballot(neg));
   if (lane == 0 && (nzero | nneg)) {
     if (nzero) atomicAdd(&info[INFO_ZERO_PIVOT], nzero);
     if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);
