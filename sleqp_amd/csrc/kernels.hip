@@ -127,15 +127,15 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// 1/d to ~1 ulp without the IEEE division sequence: hardware estimate plus two
+// 1/d to ~1 ulp without the IEEE division sequence.  v_rcp_f64 is good to 2^-24.4 on gfx950
+// (scripts/probe/rcp_f64_precision.hip), so ONE cubic step x0 (1 + e + e^2), e = 1 - d x0, leaves
+// an error of e^3 < 2^-73 before rounding: three dependent FMAs instead of the four of two
 // Newton steps.  Sits on the sequential pivot chain of the diagonal blocks.
 __device__ __forceinline__ double fast_rcp(double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, x, 1.0);
-  x = fma(x, e, x);
-  e = fma(-d, x, 1.0);
-  x = fma(x, e, x);
-  return x;
+  const double x = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, x, 1.0);
+  const double t = fma(e, e, e);
+  return fma(x, t, x);
 }
 
 struct FrontCtx {
