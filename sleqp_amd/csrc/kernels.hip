@@ -253,51 +253,76 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
 // X[i][4q..4q+3]; the cross-lane exchange goes through a 32-double LDS scratch
 // (LDS operations of one wave execute in order: a write followed by reads needs
 // no barrier).  Leaves inv(L_kk) in the block and the pivots in dd.
+// lane exchange without LDS memory: the crossbar moves registers in ONE pass, where a write
+// followed by a read costs two dependent ones
+__device__ __forceinline__ double bperm_f64(double v, int src_lane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(bits & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(bits >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// value of lane K of the own 16-lane row (swizzle bit mode: lane' = (lane & 0x10) | K in groups of 32)
+template <int K>
+__device__ __forceinline__ double rowbcast_f64(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_swizzle((int)(bits & 0xffffffffLL), 0x10 | (K << 5));
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(bits >> 32), 0x10 | (K << 5));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int K>
+__device__ __forceinline__ void diag_step(double (&a)[4], double (&x)[4], int li, int lk) {
+  constexpr int qk = K >> 2, kr = K & 3;
+  const double ck_i = bperm_f64(a[kr], (qk << 4) | li);  // A[i][k] from the lane (i, qk)
+  const double d = readlane_f64(a[kr], (qk << 4) | K);   // A[k][k] via the scalar path
+  double ckj[4], xk[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) ckj[cc] = rowbcast_f64<K>(a[cc]);  // A[k][j] = A[j][k], j = 4 lk + cc
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) xk[cc] = rowbcast_f64<K>(x[cc]);   // X[k][j]
+  const double rm = (li > K) ? fast_rcp(d) : 0.0;  // rows i <= k are finished
+  const double l_ik = ck_i * rm;
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    a[cc] = fma(-l_ik, ckj[cc], a[cc]);  // columns j <= k are dead: whatever lands there is never read
+    x[cc] = fma(-l_ik, xk[cc], x[cc]);
+  }
+}
+
 __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int lda = c.lda;
   double* A = c.A;
-  double* colk = scratch;       // 16: A[.][k] below the diagonal, 0 on and above it
-  double* xrow = scratch + 16;  // 16: X[k][.]
   double a[4], x[4];
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) {
-    a[cc] = A[(k0 + li) + (k0 + 4 * lk + cc) * lda];
-    x[cc] = (li == 4 * lk + cc) ? 1.0 : 0.0;
+    // the block is kept as a full symmetric matrix in registers: row k doubles as column k
+    const int j = 4 * lk + cc;
+    a[cc] = (li >= j) ? A[(k0 + li) + (k0 + j) * lda] : A[(k0 + j) + (k0 + li) * lda];
+    x[cc] = (li == j) ? 1.0 : 0.0;
   }
-  // The dependent chain of the whole front runs through this loop (pivot -> reciprocal ->
-  // multiplier -> update of the next pivot), so nothing else sits on it: the exchanged column is
-  // zeroed on and above the diagonal when it is written (no selects on l_ik or on the update),
-  // and singular / negative pivots are counted after the loop from the diagonal, which is
-  // final once its row has been eliminated (a zero pivot then simply floods the block with
-  // non-finite values; the factorisation is reported singular either way).
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int qk = k >> 2, kr = k & 3;
-    if (lk == qk) colk[li] = (li > k) ? a[kr] : 0.0;
-    if (li == k) {
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) xrow[4 * lk + cc] = x[cc];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double ck_i = colk[li];                         // A[i][k], i > k
-    const double d = readlane_f64(a[kr], (qk << 4) | k);  // A[k][k] via the scalar path: the
-                                                          // reciprocal chain overlaps the LDS round trip
-    double ckj[4], xk[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      ckj[cc] = colk[4 * lk + cc];  // A[j][k], j = 4 lk + cc (0 for j <= k)
-      xk[cc] = xrow[4 * lk + cc];   // X[k][j]
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double l_ik = ck_i * fast_rcp(d);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      a[cc] = fma(-l_ik, ckj[cc], a[cc]);
-      x[cc] = fma(-l_ik, xk[cc], x[cc]);
-    }
-  }
+  // The dependent chain of the whole front runs through these 16 steps (pivot -> multiplier ->
+  // update of the next pivot): one crossbar pass per step, no selects on the chain; singular /
+  // negative pivots are counted afterwards from the diagonal, which is final once its row has
+  // been eliminated (a zero pivot floods the block with non-finite values; the factorisation
+  // is reported singular either way).
+  diag_step<0>(a, x, li, lk);
+  diag_step<1>(a, x, li, lk);
+  diag_step<2>(a, x, li, lk);
+  diag_step<3>(a, x, li, lk);
+  diag_step<4>(a, x, li, lk);
+  diag_step<5>(a, x, li, lk);
+  diag_step<6>(a, x, li, lk);
+  diag_step<7>(a, x, li, lk);
+  diag_step<8>(a, x, li, lk);
+  diag_step<9>(a, x, li, lk);
+  diag_step<10>(a, x, li, lk);
+  diag_step<11>(a, x, li, lk);
+  diag_step<12>(a, x, li, lk);
+  diag_step<13>(a, x, li, lk);
+  diag_step<14>(a, x, li, lk);
+  diag_step<15>(a, x, li, lk);
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
   // pivot of column li: the diagonal entry, held by the lane (li, lk = li / 4)
