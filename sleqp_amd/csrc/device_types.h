@@ -47,6 +47,18 @@ struct FrontItem {
   PullDesc pd;
 };
 
+// one workgroup of the single-launch top-of-tree factorisation kernel
+struct TopFItem {
+  FrontItem it;
+  int role;   // 0 pivot, 1 panel, 2 Schur
+  int front;  // index of the front's counters
+  int part2;  // Schur: the second team's tile
+  int nwait;  // pivot: number of children
+  int wait_id[MAXCH];   // pivot: children
+  int wait_cnt[MAXCH];  // pivot: Schur workgroups of each child in this launch (0: finished before the launch);
+                        // Schur: [0] = panel workgroups of the front
+};
+
 // one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)
 struct TopItem {
   long long Loff, uoff, rowoff;

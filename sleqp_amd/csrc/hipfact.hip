@@ -82,9 +82,9 @@ struct LevelInfo {
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
-enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FACTOR_A, PC_FACTOR_B, PC_FACTOR_C, PC_FACTOR_D, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
+enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FACTOR_A, PC_FACTOR_B, PC_FACTOR_C, PC_FACTOR_D, PC_FACTOR_T, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
 static const char* const kProfNames[PC_COUNT] = {"memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC",
-                                                 "factorD", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"};
+                                                 "factorD", "factorT", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"};
 
 struct Prof {
   bool on = false;
@@ -128,6 +128,9 @@ struct hipfact_handle {
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 1 << 30;
+  int factor_top_max = 40;    // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int ftop_level = 1 << 30, ftop_count = 0;
+  size_t ftop_lds = 0;
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
   int pull_max_children = 4;  // <= MAXCH; 0: always the separate assembly kernel
@@ -141,7 +144,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv;
+  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -447,6 +450,84 @@ static int upload_plan(hipfact_handle* h) {
   if ((rc = upload(h, h->d_items, items))) return rc;
   if ((rc = upload(h, h->d_fitems, fitems))) return rc;
   {
+    // top-of-tree factorisation in one launch: the last levels, as long as every one of them is
+    // narrow and can pull its extend-add (no front with more than MAXCH children)
+    h->ftop_level = 1 << 30;
+    h->ftop_count = 0;
+    int lvl = P.nlevels;
+    while (lvl > 0) {
+      const LevelInfo& li = h->levels[lvl - 1];
+      int mch = 0;
+      for (int q = P.level_ptr[lvl - 1]; q < P.level_ptr[lvl]; ++q)
+        mch = std::max(mch, P.child_ptr[P.level_sn[q] + 1] - P.child_ptr[P.level_sn[q]]);
+      if (!(li.count <= h->factor_top_max && mch <= std::min(h->pull_max_children, MAXCH))) break;
+      --lvl;
+    }
+    if (P.nlevels - lvl >= 2 && h->factor_top_max > 0) {
+      auto ntiles = [&](int s) {
+        const long long u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
+        return nt * (nt + 1) / 2;
+      };
+      std::vector<TopFItem> tf;
+      size_t lds = 0;
+      for (int l = lvl; l < P.nlevels; ++l) {
+        const LevelInfo& li = h->levels[l];
+        lds = std::max({lds, li.lds_pivot, li.lds_panel});
+        auto base = [&](int s, int role, int part) {
+          TopFItem t;
+          memset(&t, 0, sizeof(t));
+          t.it.Loff = sn[s].Loff;
+          t.it.Uoff = sn[s].Uoff;
+          t.it.w = sn[s].w;
+          t.it.r = sn[s].r;
+          t.it.part = part;
+          t.it.nchild = sn[s].child_end - sn[s].child_begin;
+          t.it.pd = pulls[s];
+          t.role = role;
+          t.front = s;
+          t.part2 = part;
+          return t;
+        };
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          TopFItem t = base(s, 0, 0);
+          t.nwait = t.it.nchild;
+          for (int k = 0; k < t.nwait; ++k) {
+            const int ch = P.child_idx[sn[s].child_begin + k];
+            t.wait_id[k] = ch;
+            t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)((ntiles(ch) + 1) / 2) : 0;
+          }
+          tf.push_back(t);
+          const size_t wp = (size_t)((sn[s].w + 15) & ~15);
+          lds = std::max(lds, (wp + 2 * (size_t)(2 * 64 * 64 + 64 * MAXCH)) * sizeof(double));
+        }
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          const int u = sn[s].r - sn[s].w;
+          for (int b = 0; b < (u + 127) / 128; ++b) tf.push_back(base(s, 1, b));
+        }
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          const int u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
+          std::vector<int> tiles;
+          for (int I = 0; I < nt; ++I)
+            for (int J = 0; J <= I; ++J) tiles.push_back((I << 16) | J);
+          for (size_t k = 0; k < tiles.size(); k += 2) {
+            TopFItem t = base(s, 2, tiles[k]);
+            t.part2 = tiles[std::min(k + 1, tiles.size() - 1)];
+            t.wait_cnt[0] = (u + 127) / 128;
+            tf.push_back(t);
+          }
+        }
+      }
+      h->ftop_level = lvl;
+      h->ftop_count = (int)tf.size();
+      h->ftop_lds = lds;
+      if ((rc = upload(h, h->d_tfitems, tf))) return rc;
+      HCHECK(h, h->d_fflags.ensure(std::max<size_t>((size_t)3 * ns * sizeof(int), 16)));
+    }
+  }
+  {
     // levels merged into the single-launch top-of-tree solve: as many of the last levels as fit
     // the co-residency cap, and only if that saves at least two launches
     int lvl = P.nlevels, total = 0;
@@ -512,7 +593,8 @@ static int upload_plan(hipfact_handle* h) {
     return HIPFACT_EINTERNAL;
   }
   for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot), reinterpret_cast<const void*>(k_front_panel),
-                         reinterpret_cast<const void*>(k_front_schur), reinterpret_cast<const void*>(k_fwd_top),
+                         reinterpret_cast<const void*>(k_front_schur), reinterpret_cast<const void*>(k_factor_top),
+                         reinterpret_cast<const void*>(k_fwd_top),
                          reinterpret_cast<const void*>(k_bwd_top)})
     HCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_factor_level),
@@ -571,7 +653,8 @@ static int factor_enqueue(hipfact_handle* h) {
     LAUNCH(PC_GATHER, k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, na, h->d_Ar_src.as<int>(),
                        h->d_Kval.as<double>(), h->d_Ar_val.as<double>());
   }
-  for (int l = 0; l < P.nlevels; ++l) {
+  const int lsplit = h->debug_phases == 15 ? std::min(h->ftop_level, P.nlevels) : P.nlevels;
+  for (int l = 0; l < lsplit; ++l) {
     const LevelInfo& li = h->levels[l];
     const int* it = h->d_items.as<int>();
     const int pull = (li.pull && h->debug_phases == 15) ? 1 : 0;
@@ -593,6 +676,13 @@ static int factor_enqueue(hipfact_handle* h) {
              h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(),
              h->d_child.as<int>(), h->d_info.as<int>(), h->debug_phases);
     }
+  }
+  if (lsplit < P.nlevels) {
+    int* fl = h->d_fflags.as<int>();
+    (void)hipMemsetAsync(fl, 0, (size_t)3 * P.nsuper * sizeof(int), h->stream);
+    LAUNCH(PC_FACTOR_T, k_factor_top, dim3(h->ftop_count), dim3(512), h->ftop_lds, h->d_tfitems.as<TopFItem>(),
+           h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
+           fl + P.nsuper, fl + 2 * P.nsuper);
   }
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;
@@ -885,6 +975,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_PULL_MAX")) h->pull_max_children = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_PREFETCH")) h->top_prefetch = atoi(s);
+  if (const char* s = getenv("HIPFACT_FACTOR_TOP")) h->factor_top_max = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
@@ -1439,6 +1530,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->factored = false;
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "factor_top_max")) {  // 0: one launch per phase and level everywhere
+    h->factor_top_max = (int)value;
+    drop_graphs(h);
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "top_prefetch")) {
     h->top_prefetch = value != 0.0;
     drop_graphs(h);
@@ -1525,7 +1623,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
-  INFO("top_level", h->top_level) INFO("top_count", h->top_count) INFO("solve_timeouts", h->h_info.p ? h->h_info.as<int>()[INFO_TIMEOUT] : 0)
+  INFO("factor_top_level", h->ftop_level) INFO("factor_top_count", h->ftop_count) INFO("top_level", h->top_level) INFO("top_count", h->top_count) INFO("solve_timeouts", h->h_info.p ? h->h_info.as<int>()[INFO_TIMEOUT] : 0)
   INFO("use_graph", h->use_graph) INFO("num_graphs", h->graphs.size()) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
   INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
   INFO("rows_total", P.sn_rows.size()) INFO("ent_fused", h->ent_fused) INFO("ent_split", h->ent_split)

@@ -784,8 +784,9 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 constexpr int KC = 64;
 template <bool DD_IN_LDS>
 __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign,
-                                               const PullCtx& pc) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                               const PullCtx& pc, const int tid) {
+  // tid: thread index inside the 256-thread team that owns the tile (barriers stay workgroup-wide)
+  const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, u = c.u;
   const double* __restrict__ P21 = c.P + w;
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
     double* SJ = c.A + 64 * KC;
     const int nt = (c.u + 63) >> 6;
     for (int I = 0; I < nt; ++I)
-      for (int J = 0; J <= I; ++J) dev_schur_tile<true>(c, SI, SJ, I, J, S.child_begin == S.child_end, nopull);
+      for (int J = 0; J <= I; ++J) dev_schur_tile<true>(c, SI, SJ, I, J, S.child_begin == S.child_end, nopull, threadIdx.x);
   }
 }
 
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(FB, 2) void k_front_schur(const FrontItem* __restri
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
   const int ij = S.part;
-  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc);
+  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1556,6 +1557,88 @@ __device__ __forceinline__ void top_publish(int* __restrict__ flags, int who) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&flags[who], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Top of the elimination tree of the FACTORISATION in one launch.  The last levels hold a
+// handful of fronts each; three launches per level are then pure launch + dependent latency.
+// Here every pivot / panel / Schur work item of those levels is a workgroup of one grid, ordered
+// level by level and pivot -> panel -> Schur inside a level.  Dependencies travel through
+// counters with the agent-scope release / acquire protocol:
+//   pivot(f)  waits for all Schur workgroups of each child of f   (ddone[child] == count)
+//   panel(f)  waits for pivot(f)                                   (bdone[f] == 1)
+//   Schur(f)  waits for all panel workgroups of f                  (cdone[f] == count)
+// A workgroup only ever waits for lower-indexed ones, and workgroups are dispatched in index
+// order, so progress needs no co-residency.  Same device code, same arithmetic, same bits as
+// the per-level kernels.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void flag_wait_ge(int* __restrict__ addr, int target, int* __restrict__ info) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) {
+        atomicAdd(&info[INFO_TIMEOUT], 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void flag_publish_add(int* __restrict__ addr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(addr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// LDS: the largest of the three roles (pivot: dd | A | Y | scratch | maps; panel: dd | X | maps;
+// Schur: dd | two teams of {SI, SJ, maps})
+__global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__ items, double* __restrict__ L,
+                                                   double* __restrict__ U, int* __restrict__ info,
+                                                   const int* __restrict__ inv, const int* __restrict__ rel,
+                                                   int* __restrict__ bdone, int* __restrict__ cdone,
+                                                   int* __restrict__ ddone) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const TopFItem& T = items[blockIdx.x];
+  const FrontItem& S = T.it;
+  const FrontCtx c = make_ctx(S, L, U, lds);
+  const PullCtx pc = make_pull(S.pd, U, inv, rel, 1);
+  if (T.role == 0) {
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < T.nwait && T.wait_cnt[ch] > 0) flag_wait_ge(&ddone[T.wait_id[ch]], T.wait_cnt[ch], info);
+    dev_pivot_block<true>(c, info, 15, pc);
+    flag_publish_add(&bdone[T.front]);
+  } else if (T.role == 1) {
+    flag_wait_ge(&bdone[T.front], 1, info);
+    int* invl = reinterpret_cast<int*>(c.A + c.wp * c.lda);
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n)
+        for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
+    const int R0 = c.w + 16 * (blockDim.x >> 6) * S.part + 16 * (threadIdx.x >> 6);
+    double pv[8][4];
+    int cis[MAXCH];
+    dev_panel_rows_load(c, R0, pc, pv, cis);
+    dev_load_pivot_block(c, true);
+    if (R0 < c.r) dev_panel_rows_finish<true>(c, R0, pc, invl, pv, cis);
+    flag_publish_add(&cdone[T.front]);
+  } else {
+    flag_wait_ge(&cdone[T.front], T.wait_cnt[0], info);
+    // two 256-thread teams, one tile each (the same tile twice when the front has an odd number)
+    const int team = threadIdx.x >> 8;
+    const int ij = team ? T.part2 : S.part;
+    double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
+    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255);
+    flag_publish_add(&ddone[T.front]);
   }
 }
 

@@ -335,6 +335,32 @@ def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
 
+def test_single_launch_top_of_tree_factorisation_agrees_bitwise(fact):
+    """Per-level pivot / panel / Schur launches and the single dataflow launch for the top
+    levels run the same device code on the same data: identical bits."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 12000, 6000
+    J = synth.banded_jacobian(n, m, 20, 200, 5)  # every front of the top levels has <= 4 children
+    vi, ci, _ = synth.working_set_all_rows(n, m, 0.0, 5)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    b = np.random.default_rng(3).standard_normal(N)
+    fact.set_option("refine_steps", 0)
+    outs = []
+    for top in (0, 40, 6):
+        fact.set_option("factor_top_max", top)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert (fact.info("factor_top_level") < fact.info("nlevels")) == (top > 0)
+        for _ in range(3):  # refactor through the cached graph as well
+            fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+        assert fact.info("solve_timeouts") == 0
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    assert scaled_residual(K, outs[0], b) <= 1e-9
+
+
 def test_top_of_tree_solve_variants_agree_bitwise(fact):
     """Level-by-level solve launches, the single-launch top-of-tree kernels, and their
     panel-prefetching variant run the same arithmetic in the same order: identical bits."""
