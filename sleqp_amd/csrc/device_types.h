@@ -53,10 +53,11 @@ struct TopFItem {
   int role;   // 0 pivot, 1 panel, 2 Schur
   int front;  // index of the front's counters
   int part2;  // Schur: the second team's tile
-  int nwait;  // pivot: number of children
-  int wait_id[MAXCH];   // pivot: children
-  int wait_cnt[MAXCH];  // pivot: Schur workgroups of each child in this launch (0: finished before the launch);
-                        // Schur: [0] = panel workgroups of the front
+  int nwait;  // number of children
+  int wait_id[MAXCH];   // children
+  int wait_cnt[MAXCH];  // Schur workgroups of each child in this launch (0: finished before the launch)
+  int target;           // Schur: panel workgroups of the own front
+  int pad[3];
 };
 
 // one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)

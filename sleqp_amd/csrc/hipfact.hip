@@ -486,18 +486,18 @@ static int upload_plan(hipfact_handle* h) {
           t.role = role;
           t.front = s;
           t.part2 = part;
-          return t;
-        };
-        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-          const int s = P.level_sn[q];
-          TopFItem t = base(s, 0, 0);
           t.nwait = t.it.nchild;
           for (int k = 0; k < t.nwait; ++k) {
             const int ch = P.child_idx[sn[s].child_begin + k];
             t.wait_id[k] = ch;
             t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)((ntiles(ch) + 1) / 2) : 0;
           }
-          tf.push_back(t);
+          t.target = (sn[s].r - sn[s].w + 127) / 128;
+          return t;
+        };
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          tf.push_back(base(s, 0, 0));
           const size_t wp = (size_t)((sn[s].w + 15) & ~15);
           lds = std::max(lds, (wp + 2 * (size_t)(2 * 64 * 64 + 64 * MAXCH)) * sizeof(double));
         }
@@ -515,7 +515,6 @@ static int upload_plan(hipfact_handle* h) {
           for (size_t k = 0; k < tiles.size(); k += 2) {
             TopFItem t = base(s, 2, tiles[k]);
             t.part2 = tiles[std::min(k + 1, tiles.size() - 1)];
-            t.wait_cnt[0] = (u + 127) / 128;
             tf.push_back(t);
           }
         }

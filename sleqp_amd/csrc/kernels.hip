@@ -364,10 +364,38 @@ __device__ __forceinline__ void dev_trailing_tile(const FrontCtx& c, int k0, int
 // Blocked right-looking LDL^T (nb = 16) with look-ahead: in the trailing update of
 // step kb, wave 0 updates the next diagonal tile first and factors it at once,
 // while the other waves finish the remaining tiles.  Any number of waves >= 1.
+// Dependencies of a workgroup of the single-launch top-of-tree factorisation (k_factor_top): the
+// Schur workgroups of the children must have finished before their update matrices are read.
+// n == 0 in the per-level kernels (the launch order is the dependency).
+__device__ __forceinline__ void flag_wait_ge(int* __restrict__ addr, int target, int* __restrict__ info);
+struct ChildWait {
+  int n;
+  int* addr[MAXCH];
+  int target[MAXCH];
+  int* info;
+  __device__ __forceinline__ void wait() const {
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < n && target[ch] > 0) flag_wait_ge(addr[ch], target[ch], info);
+  }
+};
+__device__ __forceinline__ ChildWait no_wait() {
+  ChildWait cw;
+  cw.n = 0;
+  cw.info = nullptr;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    cw.addr[ch] = nullptr;
+    cw.target[ch] = 0;
+  }
+  return cw;
+}
+
 // ROWINV (8 waves): the inverse of the unit lower factor is formed block row by block row in
 // the shadow of the diagonal-block chain instead of by recursive doubling afterwards.
 template <bool ROWINV>
-__device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc) {
+__device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc,
+                                                const ChildWait& cw) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -409,6 +437,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < pc.n && tid < wp) invb[ch * wp + tid] = iv[ch];
     __syncthreads();
+    cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < pc.n) {
@@ -673,11 +702,6 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
   __syncthreads();
 }
 
-// ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
-// rows: the B operand streams from the panel (16 consecutive rows per k-step),
-// the A operand is X = inv(L11), read from LDS (fused kernel) or straight from
-// the finished panel top in L2 (split kernel: no LDS, no barrier, full
-// occupancy); results are stored row-contiguous.  Row blocks blk, blk + stride.
 // rows R0 + li of the panel: all fragments in one batch of loads (w <= 128: 32 values per lane),
 // plus the children's rows that land on them (pull mode)
 __device__ __forceinline__ void dev_panel_rows_load(const FrontCtx& c, int R0, const PullCtx& pc, double (&pv)[8][4],
@@ -699,15 +723,12 @@ __device__ __forceinline__ void dev_panel_rows_load(const FrontCtx& c, int R0, c
 }
 
 // gathers (pull mode), X P21^T on the MFMA units, scaling by D^-1, row-contiguous stores
-template <bool X_IN_LDS>
-__device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0, const PullCtx& pc, const int* invl,
+// the children's rows that land on the panel rows R0 + li (pull mode), added in child order
+__device__ __forceinline__ void dev_panel_rows_gather(const FrontCtx& c, const PullCtx& pc, const int* invl,
                                                       double (&pv)[8][4], const int (&cis)[MAXCH]) {
   const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
-  const double* A = c.A;
-  double* __restrict__ P = c.P;
-  const bool rok = (R0 + li) < r;
+  const int lk = lane >> 4;
+  const int nbk = c.nbk;
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch)
     if (ch < pc.n) {
@@ -730,6 +751,17 @@ __device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0,
 #pragma unroll
         for (int s = 0; s < 4; ++s) pv[tt][s] += g[tt][s];
     }
+}
+
+// X P21^T on the MFMA units, scaling by D^-1, row-contiguous stores
+template <bool X_IN_LDS>
+__device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0, double (&pv)[8][4]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
+  const double* A = c.A;
+  double* __restrict__ P = c.P;
+  const bool rok = (R0 + li) < r;
   d4_t acc[8];
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -762,6 +794,13 @@ __device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0,
   }
 }
 
+template <bool X_IN_LDS>
+__device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0, const PullCtx& pc, const int* invl,
+                                                      double (&pv)[8][4], const int (&cis)[MAXCH]) {
+  dev_panel_rows_gather(c, pc, invl, pv, cis);
+  dev_panel_rows_product<X_IN_LDS>(c, R0, pv);
+}
+
 // ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
 // rows: the B operand streams from the panel (16 consecutive rows per k-step),
 // the A operand is X = inv(L11) in LDS.  Row blocks blk, blk + stride, ...
@@ -782,9 +821,51 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 // (64 rows x 64 pivots per chunk, k-major) staged in LDS: 64 KB per workgroup, so
 // that two workgroups share a CU and hide each other's staging latency.
 constexpr int KC = 64;
+// children's contributions to the lane's 2 x 2 x 4 tile entries, added in child order; invs =
+// LDS copy of the children's inverse maps of the tile's rows ([0, 64)) and columns ([64, 128))
+__device__ __forceinline__ void schur_tile_gather(const PullCtx& pc, const int* invs, int i0, int j0, int li, int lk,
+                                                  double (&uv)[2][2][4]) {
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n) {
+      const double* __restrict__ Uc = pc.Uc[ch];
+      const int uc = pc.uc[ch];
+      const int* iv = invs + 128 * ch;
+      int ci[2], cj[2][4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) ci[y] = iv[i0 + 16 * y + li];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cj[x][q] = iv[64 + j0 + 16 * x + lk + 4 * q];
+      double g[2][2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // rel is monotone: i >= j in the front implies ci >= cj in the child; loads are
+            // unconditional (clamped to entry 0) so that they all leave in one batch
+            const bool ok = ci[y] >= 0 && cj[x][q] >= 0 && ci[y] >= cj[x][q];
+            const double gv = Uc[ok ? ci[y] + (long long)cj[x][q] * uc : 0];
+            g[x][y][q] = ok ? gv : 0.0;
+          }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) uv[x][y][q] += g[x][y][q];
+    }
+}
+
 template <bool DD_IN_LDS>
 __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign,
-                                               const PullCtx& pc, const int tid) {
+                                               const PullCtx& pc, const int tid, int* wait_addr = nullptr,
+                                               int wait_target = 0, int* info = nullptr) {
+  // wait_addr (single-launch top-of-tree factorisation): the children's entries are gathered
+  // first, then the panel workgroups of the own front are awaited, then the operands are staged
   // tid: thread index inside the 256-thread team that owns the tile (barriers stay workgroup-wide)
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -826,6 +907,15 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
         if (cc == ch && cc < pc.n && gi < u) ivr[h] = pc.inv[cc][w + gi];
     }
   }
+  if (wait_addr) {
+    if (pc.n > 0) {
+      invs[tid] = ivr[0];
+      invs[tid + 256] = ivr[1];
+    }
+    __syncthreads();
+    if (!idle) schur_tile_gather(pc, invs, i0, j0, li, lk, uv);
+    flag_wait_ge(wait_addr, wait_target, info);
+  }
   const int si = tid & 63;
   const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
   const double* __restrict__ pi = P21 + 64 * I + si;
@@ -852,7 +942,7 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
         }
       }
     }
-    if (kc0 == 0 && pc.n > 0) {
+    if (kc0 == 0 && pc.n > 0 && !wait_addr) {
       invs[tid] = ivr[0];
       invs[tid + 256] = ivr[1];
     }
@@ -881,39 +971,7 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     }
   }
   if (idle) return;
-#pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch)
-    if (ch < pc.n) {
-      const double* __restrict__ Uc = pc.Uc[ch];
-      const int uc = pc.uc[ch];
-      const int* iv = invs + 128 * ch;
-      int ci[2], cj[2][4];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) ci[y] = iv[i0 + 16 * y + li];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cj[x][q] = iv[64 + j0 + 16 * x + lk + 4 * q];
-      double g[2][2][4];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            // rel is monotone: i >= j in the front implies ci >= cj in the child; loads are
-            // unconditional (clamped to entry 0) so that they all leave in one batch
-            const bool ok = ci[y] >= 0 && cj[x][q] >= 0 && ci[y] >= cj[x][q];
-            const double gv = Uc[ok ? ci[y] + (long long)cj[x][q] * uc : 0];
-            g[x][y][q] = ok ? gv : 0.0;
-          }
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) uv[x][y][q] += g[x][y][q];
-    }
+  if (!wait_addr) schur_tile_gather(pc, invs, i0, j0, li, lk, uv);
   // acc[x][y][q] = update of U(i = 64 I + i0 + 16 y + li, j = 64 J + j0 + 16 x + lk + 4 q)
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -944,7 +1002,7 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
   if (!(phases & 2)) return;
   PullCtx nopull;
   nopull.n = 0;
-  dev_pivot_block<false>(c, info, phases, nopull);
+  dev_pivot_block<false>(c, info, phases, nopull, no_wait());
   dev_store_pivot_block(c);
   if (!(phases & 4)) return;
   dev_panel_solve<true>(c, 0, 1, nopull, nullptr);
@@ -978,7 +1036,7 @@ __global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
-  dev_pivot_block<true>(c, info, 15, pc);  // stores the finished tiles itself
+  dev_pivot_block<true>(c, info, 15, pc, no_wait());  // stores the finished tiles itself
 }
 
 // LDS: dd | X | MAXCH x wp ints (the children's inverse maps of the pivot columns)
@@ -1611,14 +1669,23 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
   const FrontItem& S = T.it;
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, 1);
-  if (T.role == 0) {
+  ChildWait cw;
+  cw.n = T.nwait;
+  cw.info = info;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < T.nwait && T.wait_cnt[ch] > 0) flag_wait_ge(&ddone[T.wait_id[ch]], T.wait_cnt[ch], info);
-    dev_pivot_block<true>(c, info, 15, pc);
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    cw.addr[ch] = ddone + T.wait_id[ch];
+    cw.target[ch] = T.wait_cnt[ch];
+  }
+  // In every role, whatever does not depend on the awaited workgroups is requested before the
+  // wait, so that afterwards only the awaited data is one memory round trip away.
+  if (T.role == 0) {
+    dev_pivot_block<true>(c, info, 15, pc, cw);  // waits for the children between its prefetch and its gathers
     flag_publish_add(&bdone[T.front]);
   } else if (T.role == 1) {
-    flag_wait_ge(&bdone[T.front], 1, info);
+    // panel rows incl. the children's contributions first (the children finished long ago),
+    // then the pivot workgroup of the own front is awaited and only inv(L11) remains to be read
+    cw.wait();
     int* invl = reinterpret_cast<int*>(c.A + c.wp * c.lda);
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
@@ -1628,16 +1695,21 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     double pv[8][4];
     int cis[MAXCH];
     dev_panel_rows_load(c, R0, pc, pv, cis);
+    __syncthreads();
+    dev_panel_rows_gather(c, pc, invl, pv, cis);
+    flag_wait_ge(&bdone[T.front], 1, info);
     dev_load_pivot_block(c, true);
-    if (R0 < c.r) dev_panel_rows_finish<true>(c, R0, pc, invl, pv, cis);
+    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv);
     flag_publish_add(&cdone[T.front]);
   } else {
-    flag_wait_ge(&cdone[T.front], T.wait_cnt[0], info);
-    // two 256-thread teams, one tile each (the same tile twice when the front has an odd number)
+    // two 256-thread teams, one tile each (the same tile twice when the front has an odd number):
+    // children's entries first, then the panel workgroups of the own front are awaited
+    cw.wait();
     const int team = threadIdx.x >> 8;
     const int ij = team ? T.part2 : S.part;
     double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
-    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255);
+    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255,
+                          &cdone[T.front], T.target, info);
     flag_publish_add(&ddone[T.front]);
   }
 }
