@@ -57,7 +57,8 @@ struct TopFItem {
   int wait_id[MAXCH];   // children
   int wait_cnt[MAXCH];  // Schur workgroups of each child in this launch (0: finished before the launch)
   int target;           // Schur: panel workgroups of the own front
-  int pad[3];
+  int crows;            // panel: rows per workgroup (128, or 64 with two waves per 16-row strip)
+  int pad[2];
 };
 
 // one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)

@@ -128,7 +128,8 @@ struct hipfact_handle {
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 1 << 30;
-  int factor_top_max = 40;    // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_max = 100;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
@@ -473,6 +474,8 @@ static int upload_plan(hipfact_handle* h) {
       for (int l = lvl; l < P.nlevels; ++l) {
         const LevelInfo& li = h->levels[l];
         lds = std::max({lds, li.lds_pivot, li.lds_panel});
+        // few fronts: workgroups are plentiful, so finer items shorten the per-level chain
+        const bool fine = li.count <= h->factor_top_fine;
         auto base = [&](int s, int role, int part) {
           TopFItem t;
           memset(&t, 0, sizeof(t));
@@ -490,9 +493,10 @@ static int upload_plan(hipfact_handle* h) {
           for (int k = 0; k < t.nwait; ++k) {
             const int ch = P.child_idx[sn[s].child_begin + k];
             t.wait_id[k] = ch;
-            t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)((ntiles(ch) + 1) / 2) : 0;
+            t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)(h->levels[P.sn_level[ch]].count <= h->factor_top_fine ? ntiles(ch) : (ntiles(ch) + 1) / 2) : 0;
           }
-          t.target = (sn[s].r - sn[s].w + 127) / 128;
+          t.crows = fine ? 64 : 128;
+          t.target = (sn[s].r - sn[s].w + t.crows - 1) / t.crows;
           return t;
         };
         for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
@@ -504,7 +508,8 @@ static int upload_plan(hipfact_handle* h) {
         for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
           const int s = P.level_sn[q];
           const int u = sn[s].r - sn[s].w;
-          for (int b = 0; b < (u + 127) / 128; ++b) tf.push_back(base(s, 1, b));
+          const int crows = fine ? 64 : 128;
+          for (int b = 0; b < (u + crows - 1) / crows; ++b) tf.push_back(base(s, 1, b));
         }
         for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
           const int s = P.level_sn[q];
@@ -512,9 +517,9 @@ static int upload_plan(hipfact_handle* h) {
           std::vector<int> tiles;
           for (int I = 0; I < nt; ++I)
             for (int J = 0; J <= I; ++J) tiles.push_back((I << 16) | J);
-          for (size_t k = 0; k < tiles.size(); k += 2) {
+          for (size_t k = 0; k < tiles.size(); k += (fine ? 1 : 2)) {
             TopFItem t = base(s, 2, tiles[k]);
-            t.part2 = tiles[std::min(k + 1, tiles.size() - 1)];
+            t.part2 = fine ? -1 : tiles[std::min(k + 1, tiles.size() - 1)];
             tf.push_back(t);
           }
         }
@@ -975,6 +980,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_PULL_MAX")) h->pull_max_children = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_PREFETCH")) h->top_prefetch = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_TOP")) h->factor_top_max = atoi(s);
+  if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;

@@ -754,8 +754,12 @@ __device__ __forceinline__ void dev_panel_rows_gather(const FrontCtx& c, const P
 }
 
 // X P21^T on the MFMA units, scaling by D^-1, row-contiguous stores
+// cstep / c0: this wave computes the 16-column output blocks ct == c0 (mod cstep) only (two waves
+// share a strip of rows in the top-of-tree launch, where workgroups are plentiful and the MFMA time
+// of a strip sits on the critical path)
 template <bool X_IN_LDS>
-__device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0, double (&pv)[8][4]) {
+__device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0, double (&pv)[8][4], int cstep = 1,
+                                                       int c0 = 0) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda;
@@ -872,7 +876,8 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
   const int w = c.w, r = c.r, u = c.u;
   const double* __restrict__ P21 = c.P + w;
   const int wi = wave & 1, wj = wave >> 1;
-  const bool idle = (I == J && wi < wj);  // block above the diagonal
+  const bool ghost = I < 0;  // team without a tile: takes part in the barriers only
+  const bool idle = ghost || (I == J && wi < wj);  // block above the diagonal
   const int i0 = 32 * wi, j0 = 32 * wj;
   d4_t acc[2][2];
 #pragma unroll
@@ -904,7 +909,7 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
       const int gi = (idx < 64) ? 64 * I + idx : 64 * J + idx - 64;
 #pragma unroll
       for (int cc = 0; cc < MAXCH; ++cc)
-        if (cc == ch && cc < pc.n && gi < u) ivr[h] = pc.inv[cc][w + gi];
+        if (cc == ch && cc < pc.n && gi < u && !ghost) ivr[h] = pc.inv[cc][w + gi];
     }
   }
   if (wait_addr) {
@@ -917,7 +922,7 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     flag_wait_ge(wait_addr, wait_target, info);
   }
   const int si = tid & 63;
-  const bool iok = (64 * I + si) < u, jok = (64 * J + si) < u;
+  const bool iok = !ghost && (64 * I + si) < u, jok = !ghost && (64 * J + si) < u;
   const double* __restrict__ pi = P21 + 64 * I + si;
   const double* __restrict__ pj = P21 + 64 * J + si;
   for (int kc0 = 0; kc0 < w; kc0 += KC) {
@@ -1691,7 +1696,10 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < pc.n)
         for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
-    const int R0 = c.w + 16 * (blockDim.x >> 6) * S.part + 16 * (threadIdx.x >> 6);
+    // crows = 128: one 16-row strip per wave; 64: two waves per strip, alternating output blocks
+    const int wv = threadIdx.x >> 6;
+    const int cstep = T.crows == 64 ? 2 : 1;
+    const int R0 = c.w + T.crows * S.part + 16 * (cstep == 2 ? (wv >> 1) : wv);
     double pv[8][4];
     int cis[MAXCH];
     dev_panel_rows_load(c, R0, pc, pv, cis);
@@ -1699,16 +1707,16 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     dev_panel_rows_gather(c, pc, invl, pv, cis);
     flag_wait_ge(&bdone[T.front], 1, info);
     dev_load_pivot_block(c, true);
-    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv);
+    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);
     flag_publish_add(&cdone[T.front]);
   } else {
     // two 256-thread teams, one tile each (the same tile twice when the front has an odd number):
     // children's entries first, then the panel workgroups of the own front are awaited
     cw.wait();
     const int team = threadIdx.x >> 8;
-    const int ij = team ? T.part2 : S.part;
+    const int ij = team ? T.part2 : S.part;  // part2 < 0: the second team has no tile
     double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
-    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255,
+    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij < 0 ? -1 : (ij >> 16), ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255,
                           &cdone[T.front], T.target, info);
     flag_publish_add(&ddone[T.front]);
   }
