@@ -140,7 +140,7 @@ struct hipfact_handle {
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   std::vector<LevelInfo> levels;
   // top of the tree solved in one launch per direction (levels >= top_level)
-  int top_level = 1 << 30, top_count = 0, top_max_fronts = 256;
+  int top_level = 1 << 30, top_count = 0, top_max_fronts = 1024;
   size_t top_lds_fwd = 0, top_lds_bwd = 0;
   Prof prof;
   // plan on device

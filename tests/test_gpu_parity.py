@@ -371,7 +371,7 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     b = np.random.default_rng(2).standard_normal(N)
     fact.set_option("refine_steps", 0)
     outs = []
-    for top_max, prefetch in ((0, 0), (256, 0), (256, 1)):
+    for top_max, prefetch in ((0, 0), (256, 0), (1024, 1)):
         fact.set_option("top_max_fronts", top_max)
         fact.set_option("top_prefetch", prefetch)
         fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
