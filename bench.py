@@ -164,7 +164,7 @@ def main():
         step()
     fact.synchronize()
     prof = {}
-    for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "fwd", "bwd", "rhs",
+    for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "factorT", "fwd", "bwd", "rhs",
                 "xupd", "resid", "axpy", "perm"):
         ms, cnt = fact.info(f"prof_{cls}_ms"), fact.info(f"prof_{cls}_count")
         if cnt > 0:
@@ -211,16 +211,19 @@ def main():
         fbytes, sbytes, nnzL = algorithmic_bytes(fact)
         dom = max(prof, key=lambda k: prof[k]["ms_per_step"]) if prof else "factor"
         kernel_names = {"factor": "k_factor_level", "factorA": "k_front_assemble", "factorB": "k_front_pivot",
-                        "factorC": "k_front_panel", "factorD": "k_front_schur", "fwd": "k_fwd_level",
-                        "bwd": "k_bwd_level", "mvals": "k_mvals_prod", "memset": "hipMemsetAsync(L arena)"}
+                        "factorC": "k_front_panel", "factorD": "k_front_schur", "factorT": "k_factor_top",
+                        "fwd": "k_fwd_top" if fact.info("top_level") == 0 else "k_fwd_level",
+                        "bwd": "k_bwd_top" if fact.info("top_level") == 0 else "k_bwd_level", "mvals": "k_mvals_prod",
+                        "memset": "hipMemsetAsync(L arena)"}
         launches = prof[dom]["launches_per_step"]
         # algorithmic bytes attributable to the dominant kernel, per launch:
         #   factor kernels: write L once + read it once for the updates (16 B/entry) + row indices (4 B) of the
         #   fronts that kernel family processes; the split phases A-D share their fronts' bytes.
         if dom == "factor":
             step_bytes = 16 * fact.info("ent_fused") + 4 * fact.info("rows_fused")
-        elif dom in ("factorA", "factorB", "factorC", "factorD"):
-            fam = sum(prof[k]["ms_per_step"] for k in ("factorA", "factorB", "factorC", "factorD") if k in prof)
+        elif dom in ("factorA", "factorB", "factorC", "factorD", "factorT"):
+            # the per-level kernels and the single-launch top-of-tree kernel share the fronts' bytes by time
+            fam = sum(prof[k]["ms_per_step"] for k in ("factorA", "factorB", "factorC", "factorD", "factorT") if k in prof)
             step_bytes = (16 * fact.info("ent_split") + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
         elif dom in ("fwd", "bwd"):
             step_bytes = (sbytes / 2) * prof[dom]["launches_per_step"] / max(fact.info("nlevels"), 1)
@@ -232,7 +235,7 @@ def main():
         avg_s = prof[dom]["avg_launch_us"] * 1e-6
         achieved = bytes_per_launch / avg_s / 1e9
         factor_ms = sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor", "factorA", "factorB",
-                                                          "factorC", "factorD") if k in prof)
+                                                          "factorC", "factorD", "factorT") if k in prof)
         # HBM traffic of the dominant kernel from the PMC counters (separate rocprofv3 --pmc passes of this
         # same command, profiles/r1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
         traffic = None
