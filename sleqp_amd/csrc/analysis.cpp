@@ -202,6 +202,11 @@ void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
   std::vector<int> col2sn(m);
   for (int s = 0; s < ns; ++s)
     for (int k = 0; k < sn[s].w; ++k) col2sn[sn[s].c0 + k] = s;
+  // children per supernode: a merged front inherits the children of both, and the device keeps
+  // fronts with at most max_children children on its fast (pull-mode / single-launch) path
+  std::vector<int> nch(ns, 0);
+  for (int s = 0; s < ns; ++s)
+    if ((int)sn[s].rows.size() > sn[s].w) ++nch[col2sn[sn[s].rows[sn[s].w]]];
   for (int s = 0; s + 1 < ns; ++s) {
     RawSuper& a = sn[s];
     if ((int)a.rows.size() == a.w) continue;  // root
@@ -210,6 +215,7 @@ void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
     RawSuper& b = sn[p];
     const int wm = a.w + b.w;
     if (wm > prm.wmax) continue;
+    if (prm.max_children > 0 && nch[p] - 1 + nch[s] > std::max(prm.max_children, nch[p])) continue;
     const int64_t ua = (int64_t)a.rows.size() - a.w;
     const int64_t rb = (int64_t)b.rows.size();
     const int64_t zeros = a.zeros + b.zeros + (int64_t)a.w * (rb - ua);
@@ -233,6 +239,7 @@ void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
     b.c0 = a.c0;
     b.w = wm;
     b.zeros = zeros;
+    nch[p] += nch[s] - 1;
     a.dead = true;
     std::vector<int>().swap(a.rows);
   }
@@ -283,6 +290,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   if (const char* e = getenv("HIPFACT_ORDERING")) prm.ordering = atoi(e);
   if (const char* e = getenv("HIPFACT_ND_LEAF")) prm.nd_leaf = atoi(e);
   if (const char* e = getenv("HIPFACT_WMAX")) prm.wmax = atoi(e);
+  if (const char* e = getenv("HIPFACT_MAX_CHILDREN")) prm.max_children = atoi(e);
   if (const char* e = getenv("HIPFACT_ND_SEP_FRAC")) prm.nd_sep_frac = atof(e);
   if (const char* e = getenv("HIPFACT_RELAX")) {
     double a, b, c;

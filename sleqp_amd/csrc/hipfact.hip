@@ -1579,6 +1579,8 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->prm.ordering = (int)value;
   else if (!strcmp(name, "wmax"))
     h->prm.wmax = (int)value;
+  else if (!strcmp(name, "max_children"))
+    h->prm.max_children = (int)value;
   else if (!strcmp(name, "nd_leaf"))
     h->prm.nd_leaf = (int)value;
   else if (!strcmp(name, "nd_sep_frac"))

@@ -33,6 +33,7 @@ struct PlanParams {
   double relax_small = 0.6;   // merged width <= 32
   double relax_mid = 0.4;     // ... <= 64
   double relax_big = 0.3;     // ... wider
+  int max_children = 4;       // merges must not create fronts with more children (0 = unlimited); = MAXCH of the device
   bool force_generic = false;
 };
 
