@@ -111,6 +111,7 @@ struct hipfact_handle {
   PlanParams prm;
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
+  bool prod_packed = false;  // product lists as one packed word per pair
   bool idx32 = false;  // product-list pointers and panel targets fit 32 bits
   int refine_steps = 1;
   bool refine_adaptive = true;   // run the correction pass only when the residual asks for it
@@ -308,8 +309,24 @@ static int upload_plan(hipfact_handle* h) {
       if ((rc = upload(h, h->d_prod_ptr, p32))) return rc;
     } else if ((rc = upload(h, h->d_prod_ptr, P.prod_ptr)))
       return rc;
-    if ((rc = upload(h, h->d_prod_a, P.prod_a))) return rc;
-    if ((rc = upload(h, h->d_prod_b, P.prod_b))) return rc;
+    {
+      // one packed word per product when every pair fits (see prod_pair)
+      h->prod_packed = P.nnzK < (1LL << 24);
+      const size_t np = P.prod_a.size();
+      for (size_t p = 0; p < np && h->prod_packed; ++p)
+        if (std::abs(P.prod_a[p] - P.prod_b[p]) > 255) h->prod_packed = false;
+      if (h->prod_packed) {
+        std::vector<int> pk(np);
+        for (size_t p = 0; p < np; ++p)
+          pk[p] = (int)(((unsigned int)std::min(P.prod_a[p], P.prod_b[p]) << 8) |
+                        (unsigned int)std::abs(P.prod_a[p] - P.prod_b[p]));
+        if ((rc = upload(h, h->d_prod_a, pk))) return rc;
+        h->d_prod_b.release();
+      } else {
+        if ((rc = upload(h, h->d_prod_a, P.prod_a))) return rc;
+        if ((rc = upload(h, h->d_prod_b, P.prod_b))) return rc;
+      }
+    }
     if ((rc = upload(h, h->d_Ar_ptr, P.Ar_ptr))) return rc;
     if ((rc = upload(h, h->d_Ar_col, P.Ar_col))) return rc;
     if ((rc = upload(h, h->d_Ar_src, P.Ar_src))) return rc;
@@ -639,14 +656,19 @@ static int factor_enqueue(hipfact_handle* h) {
   const long long nM = (long long)P.Mi.size();
   if (nM > 0) {
     if (P.saddle) {
-      if (h->idx32)
-        LAUNCH(PC_MVALS, k_mvals_prod<unsigned int>, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
-               h->d_prod_ptr.as<unsigned int>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
-               h->d_Mtarget.as<unsigned int>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+#define MVALS_LAUNCH(IDX, PK)                                                                                 \
+  LAUNCH(PC_MVALS, (k_mvals_prod<IDX, PK>), dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM, h->d_prod_ptr.as<IDX>(), \
+         h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), h->d_Mtarget.as<IDX>(), h->d_Kval.as<double>(),           \
+         h->d_L.as<double>())
+      if (h->idx32 && h->prod_packed)
+        MVALS_LAUNCH(unsigned int, true);
+      else if (h->idx32)
+        MVALS_LAUNCH(unsigned int, false);
+      else if (h->prod_packed)
+        MVALS_LAUNCH(long long, true);
       else
-        LAUNCH(PC_MVALS, k_mvals_prod<long long>, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM,
-               h->d_prod_ptr.as<long long>(), h->d_prod_a.as<int>(), h->d_prod_b.as<int>(),
-               h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
+        MVALS_LAUNCH(long long, false);
+#undef MVALS_LAUNCH
     } else {
       LAUNCH(PC_MVALS, k_mvals_src, dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM, h->d_src.as<int>(),
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());

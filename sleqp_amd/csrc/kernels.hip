@@ -33,7 +33,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Saddle mode: elimination of the n leaf columns x of K = [I A^T; A 0].
 // M(i,k) = S(i,k) = sum_j A(i,j) A(k,j), summed in the fixed order of the
 // product list (deterministic), written straight into its front panel.
-template <class IDX>
+// PACKED: one word per product, (min(a, b) << 8) | |a - b| — both factors sit in the same column
+// of K, a few entries apart, so the pair usually fits (halves the index traffic, which is what this
+// kernel moves: its K values stay in L2).
+template <bool PACKED>
+__device__ __forceinline__ void prod_pair(const int* __restrict__ prod_a, const int* __restrict__ prod_b, long long p,
+                                          int& a, int& b) {
+  if (PACKED) {
+    const unsigned int pk = (unsigned int)prod_a[p];
+    a = (int)(pk >> 8);
+    b = a + (int)(pk & 255u);
+  } else {
+    a = prod_a[p];
+    b = prod_b[p];
+  }
+}
+
+template <class IDX, bool PACKED>
 __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __restrict__ prod_ptr,
                                                    const int* __restrict__ prod_a, const int* __restrict__ prod_b,
                                                    const IDX* __restrict__ target, const double* __restrict__ Kval,
@@ -48,11 +64,7 @@ __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __re
       int a[4], b[4];
       double x[4], y[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long p = (p0 + q < p1) ? p0 + q : p1 - 1;
-        a[q] = prod_a[p];
-        b[q] = prod_b[p];
-      }
+      for (int q = 0; q < 4; ++q) prod_pair<PACKED>(prod_a, prod_b, (p0 + q < p1) ? p0 + q : p1 - 1, a[q], b[q]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         x[q] = Kval[a[q]];
@@ -61,15 +73,15 @@ __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __re
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (p0 + q < p1) s = fma(x[q], y[q], s);
-      for (long long p = p0 + 4; p < p1; ++p) s = fma(Kval[prod_a[p]], Kval[prod_b[p]], s);
+      for (long long p = p0 + 4; p < p1; ++p) {
+        int pa, pb;
+        prod_pair<PACKED>(prod_a, prod_b, p, pa, pb);
+        s = fma(Kval[pa], Kval[pb], s);
+      }
     }
     L[tgt] = s;
   }
 }
-template __global__ void k_mvals_prod<long long>(long long, const long long*, const int*, const int*,
-                                                 const long long*, const double*, double*);
-template __global__ void k_mvals_prod<unsigned int>(long long, const unsigned int*, const int*, const int*,
-                                                    const unsigned int*, const double*, double*);
 
 // Generic mode: M(e) = K(src[e]).
 __global__ __launch_bounds__(FB) void k_mvals_src(long long nM, const int* __restrict__ src,
