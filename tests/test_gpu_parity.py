@@ -71,6 +71,39 @@ def test_factor_solve_vs_oracle(fact, n, m, kind, frac, refine):
     assert rel_err(sv.to_raw(), oracle.vec_to_raw(N, oi, od)) <= REL_TOL
 
 
+def test_random_sweep_vs_oracle(fact):
+    """Seeded sweep over shapes, densities, active bounds and kernel configurations (per-level
+    launches / single-launch top of the tree, pull / scatter extend-add): every solution against
+    the dense LAPACK-restating oracle."""
+    from sleqp_amd.sparse import SleqpMat
+
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        n = int(rng.integers(20, 600))
+        m = int(rng.integers(1, max(2, n // 2)))
+        kind = "b" if trial % 2 else "u"
+        frac = float(rng.choice([0.0, 0.05, 0.3]))
+        J, vi, ci, W = _problem(n, m, kind, frac, 100 + trial)
+        if W > n:
+            continue
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        cond = np.linalg.cond(K.toarray())
+        if not np.isfinite(cond) or cond > 1e7:
+            continue  # (numerically) dependent working set: covered by test_error_behaviour
+        ref = oracle.OracleFact(N, kc, kr, kd)
+        fact.set_option("factor_top_max", [100, 0, 6][trial % 3])
+        fact.set_option("pull_max_children", [4, 0][(trial // 3) % 2])
+        fact.set_option("refine_steps", 1)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        b = rng.standard_normal(N)
+        ref.solve_dense(b)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert rel_err(z, ref.raw_solution()) <= 1e-9 * max(1.0, cond * 1e-3), (trial, n, m, kind, frac, cond)
+        assert scaled_residual(K, z, b) <= 1e-11, (trial, n, m, kind, frac)
+
+
 def test_reference_known_answers_on_device(fact):
     """constrained_newton_test.c:204-275, unconstrained_newton_test.c:67-205 and
     dual_estimation_test.c:15-103 known answers, reproduced through the device backend."""
