@@ -373,7 +373,7 @@ static int upload_plan(hipfact_handle* h) {
     }
     const size_t wp = (size_t)((mw + 15) & ~15);
     const size_t needB = wp * (wp + 1) + 16 * (wp + 1) + 32;
-    const size_t needD = (size_t)128 * 64;  // two 64 x 64 operand strips
+    const size_t needD = (size_t)128 * 32;  // two 64 x KC operand strips
     li.lds_factor = (wp + std::max(needB, needD)) * sizeof(double);
     li.lds_pivot = (wp + needB) * sizeof(double) + MAXCH * wp * sizeof(int);
     li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double) + MAXCH * wp * sizeof(int);
@@ -520,7 +520,7 @@ static int upload_plan(hipfact_handle* h) {
           const int s = P.level_sn[q];
           tf.push_back(base(s, 0, 0));
           const size_t wp = (size_t)((sn[s].w + 15) & ~15);
-          lds = std::max(lds, (wp + 2 * (size_t)(2 * 64 * 64 + 64 * MAXCH)) * sizeof(double));
+          lds = std::max(lds, (wp + 2 * (size_t)(2 * 64 * 32 + 64 * MAXCH)) * sizeof(double));
         }
         for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
           const int s = P.level_sn[q];

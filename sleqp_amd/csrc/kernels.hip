@@ -836,7 +836,7 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
 // ---- phase D: one 64 x 64 tile (I, J) of U_s -= L21 D L21^T.  Operand strips
 // (64 rows x 64 pivots per chunk, k-major) staged in LDS: 64 KB per workgroup, so
 // that two workgroups share a CU and hide each other's staging latency.
-constexpr int KC = 64;
+constexpr int KC = 32;
 // children's contributions to the lane's 2 x 2 x 4 tile entries, added in child order; invs =
 // LDS copy of the children's inverse maps of the tile's rows ([0, 64)) and columns ([64, 128))
 __device__ __forceinline__ void schur_tile_gather(const PullCtx& pc, const int* invs, int i0, int j0, int li, int lk,
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict
 }
 
 // part = (I << 16) | J
-__global__ __launch_bounds__(FB, 2) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
+__global__ __launch_bounds__(FB, 3) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
                                                     double* __restrict__ U, const int* __restrict__ inv,
                                                     const int* __restrict__ rel, int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
