@@ -422,8 +422,15 @@ static int upload_plan(hipfact_handle* h) {
         it.pd = pulls[s];
         return it;
       };
+      // widest fronts first: a level lasts as long as its slowest front, which must not be the
+      // one that had to wait for a free CU
+      std::vector<int> order(P.level_sn.begin() + P.level_ptr[l], P.level_sn.begin() + P.level_ptr[l + 1]);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const long long wa = sn[a].w, wb = sn[b].w;
+        return wa != wb ? wa > wb : sn[a].r > sn[b].r;
+      });
       li.itB = (long long)fitems.size();
-      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) fitems.push_back(item(P.level_sn[q], 0));
+      for (int s : order) fitems.push_back(item(s, 0));
       li.itC = (long long)fitems.size();
       {
         // 128 panel rows per workgroup (8 waves); 64 when that leaves most of the chip idle
@@ -435,8 +442,7 @@ static int upload_plan(hipfact_handle* h) {
         li.panel_threads = (blocks128 < h->panel_small_below) ? 256 : 512;
       }
       const int prow = li.panel_threads / 4;
-      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-        const int s = P.level_sn[q];
+      for (int s : order) {
         const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
         for (int b = 0; b < (u + prow - 1) / prow; ++b) {
           fitems.push_back(item(s, b));
@@ -444,8 +450,7 @@ static int upload_plan(hipfact_handle* h) {
         }
       }
       li.itD = (long long)fitems.size();
-      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-        const int s = P.level_sn[q];
+      for (int s : order) {
         const int u = P.sn_r[s] - (P.sn_c0[s + 1] - P.sn_c0[s]);
         const int nt = (u + 63) / 64;
         for (int I = 0; I < nt; ++I)
