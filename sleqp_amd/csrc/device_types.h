@@ -72,8 +72,16 @@ struct TopItem {
   long long c_reloff[MAXCH]; // children's relative indices
   int c_uc[MAXCH];
   int c_id[MAXCH];
-  int c_wait[MAXCH];         // child is part of the same launch: wait for its flag
+  int c_wait[MAXCH];         // child is part of the same launch: wait until its flag reaches this count (0: no wait)
+  // wide fronts (thousands of update rows): one "head" workgroup (pivot block) and several "slice"
+  // workgroups (256 update rows each) instead of one workgroup that streams the whole panel
+  int kind;                  // 0 ordinary front, 1 head, 2 slice
+  int a0, a1;                // slice: update rows [a0, a1)
+  int nsl;                   // number of slices of the front
+  long long poff;            // backward: the front's partial sums (nsl x w) in the scratch buffer
+  int c_invoff[MAXCH];       // children's inverse relative indices
 };
+constexpr int WIDE_SLICE_ROWS = 256;
 constexpr int TOP_REL_CAP = 2048;   // ints of children's relative indices staged in LDS
 constexpr int TOP_L21_CAP = 16384;  // doubles of L21 (forward) / inv(L11) (backward) staged in LDS
 

@@ -133,6 +133,7 @@ struct hipfact_handle {
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
+  int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
   int pull_max_children = 4;  // <= MAXCH; 0: always the separate assembly kernel
@@ -146,7 +147,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags;
+  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags, d_ftarget, d_wpart;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -566,6 +567,22 @@ static int upload_plan(hipfact_handle* h) {
       std::vector<int> top;
       std::vector<TopItem> titems;
       h->top_lds_fwd = h->top_lds_bwd = 0;
+      // wide fronts: a head and slices of WIDE_SLICE_ROWS update rows; the flag of such a front
+      // counts its slices in the forward pass
+      std::vector<int> ftarget(ns, 1);
+      auto wide_slices = [&](int s) {
+        const long long u = sn[s].r - sn[s].w;
+        const int nch = sn[s].child_end - sn[s].child_begin;
+        return (h->wide_min_rows > 0 && u >= h->wide_min_rows && nch <= MAXCH)
+                   ? (int)((u + WIDE_SLICE_ROWS - 1) / WIDE_SLICE_ROWS)
+                   : 0;
+      };
+      for (int l = lvl; l < P.nlevels; ++l)
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int nsl = wide_slices(P.level_sn[q]);
+          if (nsl > 0) ftarget[P.level_sn[q]] = nsl;
+        }
+      long long wpart_size = 0;
       for (int l = lvl; l < P.nlevels; ++l) {
         for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
           const int s = P.level_sn[q];
@@ -590,7 +607,8 @@ static int upload_plan(hipfact_handle* h) {
             T.c_reloff[k] = sn[ch].reloff;
             T.c_uc[k] = sn[ch].r - sn[ch].w;
             T.c_id[k] = ch;
-            T.c_wait[k] = P.sn_level[ch] >= lvl;
+            T.c_invoff[k] = sn[ch].pad1;
+            T.c_wait[k] = P.sn_level[ch] >= lvl ? ftarget[ch] : 0;
             sum_uc += T.c_uc[k];
             max_uc = std::max<long long>(max_uc, T.c_uc[k]);
           }
@@ -604,15 +622,36 @@ static int upload_plan(hipfact_handle* h) {
             const size_t wp16 = (size_t)((T.w + 15) & ~15);
             lb = ((size_t)u + 4 + 2 * wp16 + 4 + 256 + (size_t)((u + 1) / 2) + (size_t)T.w * T.w + 2) * sizeof(double);
           }
+          const int nsl = wide_slices(s);
+          if (nsl > 0) {
+            T.prefetch = 0;
+            T.kind = 1;
+            T.nsl = nsl;
+            T.poff = wpart_size;
+            wpart_size += (long long)nsl * T.w;
+            lf = lb = ((size_t)10 * T.w + WIDE_SLICE_ROWS + 1024 + 2) * sizeof(double);
+            titems.push_back(T);
+            for (int q2 = 0; q2 < nsl; ++q2) {
+              TopItem S2 = T;
+              S2.kind = 2;
+              S2.a0 = q2 * WIDE_SLICE_ROWS;
+              S2.a1 = (int)std::min<long long>(u, (long long)(q2 + 1) * WIDE_SLICE_ROWS);
+              titems.push_back(S2);
+            }
+          } else {
+            titems.push_back(T);
+          }
           h->top_lds_fwd = std::max(h->top_lds_fwd, lf);
           h->top_lds_bwd = std::max(h->top_lds_bwd, lb);
-          titems.push_back(T);
         }
       }
+      h->top_count = (int)titems.size();
+      if ((rc = upload(h, h->d_ftarget, ftarget))) return rc;
+      HCHECK(h, h->d_wpart.ensure(std::max<size_t>((size_t)wpart_size * sizeof(double), 16)));
       if ((rc = upload(h, h->d_top_sn, top))) return rc;
       if ((rc = upload(h, h->d_titems, titems))) return rc;
     }
-    HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)ns * sizeof(int), 16)));
+    HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)2 * ns * sizeof(int), 16)));
   }
   if (max_lds > 160 * 1024) {
     h->error = "front too large for LDS-resident solve vectors";
@@ -755,14 +794,15 @@ static void solve_m_async(hipfact_handle* h) {
            h->d_y.as<double>(), h->d_uvec.as<double>());
   }
   if (ltop < P.nlevels) {
-    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
+    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)2 * P.nsuper * sizeof(int), h->stream);
     LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
-           h->d_y.as<double>(), h->d_uvec.as<double>(), h->d_flags.as<int>(), h->d_info.as<int>());
-    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)P.nsuper * sizeof(int), h->stream);
+           h->d_inv.as<int>(), h->d_ftarget.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>(),
+           h->d_flags.as<int>(), h->d_flags.as<int>() + P.nsuper, h->d_info.as<int>());
+    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)2 * P.nsuper * sizeof(int), h->stream);
     LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
-           h->d_flags.as<int>(), h->d_info.as<int>());
+           h->d_wpart.as<double>(), h->d_flags.as<int>(), h->d_flags.as<int>() + P.nsuper, h->d_info.as<int>());
   }
   for (int l = ltop - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];
@@ -1006,6 +1046,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_SPLIT_MAX")) h->split_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_PULL_MAX")) h->pull_max_children = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_PREFETCH")) h->top_prefetch = atoi(s);
+  if (const char* s = getenv("HIPFACT_WIDE_MIN")) h->wide_min_rows = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_TOP")) h->factor_top_max = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
@@ -1564,6 +1605,13 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "factor_top_max")) {  // 0: one launch per phase and level everywhere
     h->factor_top_max = (int)value;
+    drop_graphs(h);
+    h->have_plan = false;
+    h->factored = false;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "wide_min_rows")) {
+    h->wide_min_rows = (int)value;
     drop_graphs(h);
     h->have_plan = false;
     h->factored = false;

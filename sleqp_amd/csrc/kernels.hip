@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void dev_fwd_front(const SnDesc& S, const SnDesc* __r
 }
 
 
-__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info);
+__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info, int target = 1);
 
 // Forward step of one front inside the single-launch top-of-tree kernel.  Everything that does
 // not depend on the children is requested BEFORE the wait for their flags: own right-hand side,
@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch)
     if (ch < T.nchild && T.c_wait[ch]) {
-      top_wait(flags, T.c_id[ch], info);
+      top_wait(flags, T.c_id[ch], info, T.c_wait[ch]);
       waited = true;
     }
   if (!waited) __syncthreads();
@@ -1609,10 +1609,10 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
 // Flags are zeroed by a memset node before every launch.  A spin that runs out
 // sets INFO_TIMEOUT instead of hanging the GPU.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info) {
+__device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info, int target) {
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_load(&flags[who], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+    while (__hip_atomic_load(&flags[who], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1 << 22)) {
         atomicAdd(&info[INFO_TIMEOUT], 1);
@@ -1625,6 +1625,15 @@ __device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* 
   __syncthreads();
 }
 
+__device__ __forceinline__ void top_publish_add(int* __restrict__ flags, int who) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&flags[who], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __device__ __forceinline__ void top_publish(int* __restrict__ flags, int who) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
   __syncthreads();
@@ -1734,21 +1743,223 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
   }
 }
 
+// ---- wide fronts in the single-launch solves.  A front with thousands of update rows streams
+// megabytes of L21 per solve; one workgroup moves that at the bandwidth of one CU.  Such a front
+// is split into a head (pivot block: the two small triangular products) and slices of
+// WIDE_SLICE_ROWS update rows (the rectangular products), one workgroup each:
+//   forward   head: f_top += children, x = inv(L11) f_top            -> hflags[F] = 1
+//             slice: waits for the head; u[a] = f_below[a] - L21[a, :] x   -> flags[F] += 1   (F done at nsl)
+//   backward  slice: waits for the parent; partial_s = L21[slice, :]^T g   -> hflags[F] += 1
+//             head: waits for its slices; v = z / d - sum_s partial_s (fixed order), x = v + lower(inv(L11))^T v
+//                                                                     -> flags[F] = 1
+// Children's contributions are gathered through the inverse relative indices (no scatter, child order).
+__device__ __forceinline__ void dev_fwd_wide_head(const TopItem& T, const double* __restrict__ L,
+                                                  const int* __restrict__ rel, double* __restrict__ y,
+                                                  const double* __restrict__ uvec, double* lds) {
+  const int tid = threadIdx.x;
+  const int w = T.w, r = T.r;
+  const double* __restrict__ P = L + T.Loff;
+  double* f = lds;       // w
+  double* ps = f + w;    // 8 x w partial sums
+  for (int t = tid; t < w; t += SB) f[t] = y[T.c0 + t];
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < T.nchild) {
+      // the child's update rows that land in the pivot rows are its leading ones (rel is monotone)
+      const int* __restrict__ rc = rel + T.c_reloff[ch];
+      const double* __restrict__ uv = uvec + T.c_uoff[ch];
+      for (int a = tid; a < min(T.c_uc[ch], w); a += SB) {
+        const int q = rc[a];
+        if (q < w) f[q] += uv[a];
+      }
+      __syncthreads();
+    }
+  {
+    const int k = tid & 127, p = tid >> 7;
+    if (k < w) {
+      const int lo = (int)(((long long)k * p) >> 3), hi = (int)(((long long)k * (p + 1)) >> 3);
+      const double* Xk = P + k;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int t = lo;
+      for (; t + 3 < hi; t += 4) {
+        s0 += Xk[(long long)t * r] * f[t];
+        s1 += Xk[(long long)(t + 1) * r] * f[t + 1];
+        s2 += Xk[(long long)(t + 2) * r] * f[t + 2];
+        s3 += Xk[(long long)(t + 3) * r] * f[t + 3];
+      }
+      for (; t < hi; ++t) s0 += Xk[(long long)t * r] * f[t];
+      ps[p * w + k] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < w; k += SB) {
+    double s = f[k];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s += ps[p * w + k];
+    y[T.c0 + k] = s;
+  }
+}
+
+// lds: w | WIDE_SLICE_ROWS | 1024
+__device__ __forceinline__ void dev_fwd_wide_slice(const TopItem& T, const double* __restrict__ L,
+                                                   const int* __restrict__ inv, const double* __restrict__ y,
+                                                   double* __restrict__ uvec, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = T.w, r = T.r;
+  const int us = T.a1 - T.a0;  // <= WIDE_SLICE_ROWS
+  const double* __restrict__ P = L + T.Loff + w + T.a0;
+  double* xs = lds;
+  double* fb = xs + w;
+  double* part = fb + WIDE_SLICE_ROWS;
+  for (int k = tid; k < w; k += SB) xs[k] = y[T.c0 + k];
+  for (int a = tid; a < us; a += SB) {
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < T.nchild) {
+        const int ia = inv[T.c_invoff[ch] + w + T.a0 + a];
+        if (ia >= 0) s += uvec[T.c_uoff[ch] + ia];
+      }
+    fb[a] = s;
+  }
+  __syncthreads();
+  // 64-row chunks x column slices, fixed-order reduction (as dev_fwd_front)
+  const int nchunk = (us + 63) >> 6;           // <= 4
+  const int nslice = 16 / nchunk;
+  const int ch = wave % nchunk, sl = wave / nchunk;
+  if (sl < nslice) {
+    const int a = (ch << 6) + lane;
+    const int lo = (int)(((long long)w * sl) / nslice), hi = (int)(((long long)w * (sl + 1)) / nslice);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (a < us) {
+      const double* Lr = P + a;
+      int k = lo;
+      for (; k + 3 < hi; k += 4) {
+        s0 += Lr[(long long)k * r] * xs[k];
+        s1 += Lr[(long long)(k + 1) * r] * xs[k + 1];
+        s2 += Lr[(long long)(k + 2) * r] * xs[k + 2];
+        s3 += Lr[(long long)(k + 3) * r] * xs[k + 3];
+      }
+      for (; k < hi; ++k) s0 += Lr[(long long)k * r] * xs[k];
+    }
+    part[sl * (nchunk << 6) + (ch << 6) + lane] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  double* __restrict__ uo = uvec + T.uoff + T.a0;
+  for (int a = tid; a < us; a += SB) {
+    double s = 0.0;
+    for (int sl2 = 0; sl2 < nslice; ++sl2) s += part[sl2 * (nchunk << 6) + a];
+    uo[a] = fb[a] - s;
+  }
+}
+
+// lds: WIDE_SLICE_ROWS
+__device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const double* __restrict__ L,
+                                                   const int* __restrict__ rows, const double* __restrict__ y,
+                                                   double* __restrict__ wpart, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = T.w, r = T.r;
+  const int us = T.a1 - T.a0;
+  const double* __restrict__ P = L + T.Loff + w + T.a0;
+  const int* __restrict__ rw = rows + T.rowoff + w + T.a0;
+  double* g = lds;
+  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) g[a] = (a < us) ? y[rw[a]] : 0.0;
+  __syncthreads();
+  // wave: 8 columns, lanes: rows lane + 64 q; shuffle tree per column (fixed order)
+  double s[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int k = 8 * wave + cc;
+    s[cc] = 0.0;
+    if (k < w) {
+      const double* col = P + (long long)k * r;
+#pragma unroll
+      for (int q = 0; q < WIDE_SLICE_ROWS / 64; ++q) {
+        const int a = lane + 64 * q;
+        if (a < us) s[cc] += col[a] * g[a];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) s[cc] += __shfl_down(s[cc], o, 64);
+  }
+  if (lane == 0) {
+    const int sidx = T.a0 / WIDE_SLICE_ROWS;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int k = 8 * wave + cc;
+      if (k < w) wpart[T.poff + (long long)sidx * w + k] = s[cc];
+    }
+  }
+}
+
+// lds: 2 w
+__device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double* __restrict__ L,
+                                                  double* __restrict__ y, const double* __restrict__ wpart,
+                                                  double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = T.w, r = T.r;
+  const double* __restrict__ P = L + T.Loff;
+  double* v = lds;
+  for (int k = tid; k < w; k += SB) {
+    double s = 0.0;
+    for (int q = 0; q < T.nsl; ++q) s += wpart[T.poff + (long long)q * w + k];
+    v[k] = y[T.c0 + k] / P[k + (long long)k * r] - s;
+  }
+  __syncthreads();
+  // x_k = v_k + inv(L11)(:,k)^T v below the diagonal: wave: 8 columns, lanes: rows k + 1 + lane + 64 q
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int k = 8 * wave + cc;
+    double s = 0.0;
+    if (k < w) {
+      const double* col = P + (long long)k * r;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = k + 1 + lane + 64 * q;
+        if (t < w) s += col[t] * v[t];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0 && k < w) y[T.c0 + k] = v[k] + s;
+  }
+}
+
 // titems: fronts of the levels >= top_level, children before parents
 __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, const TopItem* __restrict__ titems,
                                                 int top_level, const double* __restrict__ L,
                                                 const int* __restrict__ rel, const int* __restrict__ child_idx,
+                                                const int* __restrict__ inv, const int* __restrict__ ftarget,
                                                 double* __restrict__ y, double* __restrict__ uvec,
-                                                int* __restrict__ flags, int* __restrict__ info) {
+                                                int* __restrict__ flags, int* __restrict__ hflags,
+                                                int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TopItem& T = titems[blockIdx.x];
+  if (T.kind != 0) {
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < T.nchild && T.c_wait[ch]) top_wait(flags, T.c_id[ch], info, T.c_wait[ch]);
+    if (T.kind == 1) {
+      dev_fwd_wide_head(T, L, rel, y, uvec, lds);
+      top_publish(hflags, T.s);
+    } else {
+      top_wait(hflags, T.s, info, 1);
+      dev_fwd_wide_slice(T, L, inv, y, uvec, lds);
+      top_publish_add(flags, T.s);
+    }
+    return;
+  }
   if (T.prefetch & 1) {
     dev_fwd_front_top(T, L, rel, y, uvec, lds, flags, info);
   } else {
     const SnDesc S = sn[T.s];
     for (int ci = S.child_begin; ci < S.child_end; ++ci) {
       const int c = child_idx[ci];
-      if (sn[c].pad0 >= top_level) top_wait(flags, c, info);
+      if (sn[c].pad0 >= top_level) top_wait(flags, c, info, ftarget[c]);
     }
     dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
   }
@@ -1757,12 +1968,28 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
 
 __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, const TopItem* __restrict__ titems,
                                                 const double* __restrict__ L, const int* __restrict__ rows,
-                                                double* __restrict__ y, int* __restrict__ flags,
+                                                double* __restrict__ y, double* __restrict__ wpart,
+                                                int* __restrict__ flags, int* __restrict__ hflags,
                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // parents before children: workgroups are dispatched in index order, so a front never waits
   // for one that has not been dispatched yet (no co-residency assumption for correctness)
   const TopItem& T = titems[gridDim.x - 1 - blockIdx.x];
+  if (T.kind == 2) {
+    if (T.parent >= 0) top_wait(flags, T.parent, info, 1);
+    dev_bwd_wide_slice(T, L, rows, y, wpart, lds);
+    top_publish_add(hflags, T.s);
+    return;
+  }
+  if (T.kind == 1) {
+    if (T.nsl > 0)
+      top_wait(hflags, T.s, info, T.nsl);  // the slices waited for the parent
+    else if (T.parent >= 0)
+      top_wait(flags, T.parent, info, 1);
+    dev_bwd_wide_head(T, L, y, wpart, lds);
+    top_publish(flags, T.s);
+    return;
+  }
   if (T.prefetch & 2) {
     dev_bwd_small<true>(T.Loff, T.rowoff, T.c0, T.w, T.r, T.parent, L, rows, y, lds, flags, info);
   } else {

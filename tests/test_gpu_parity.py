@@ -394,6 +394,32 @@ def test_single_launch_top_of_tree_factorisation_agrees_bitwise(fact):
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
 
+def test_wide_fronts_solved_by_several_workgroups(fact):
+    """Fronts with many update rows are split into a head and row slices in the single-launch
+    solves (dense Schur complements, BASELINE configs[2] family): against the one-workgroup
+    path and the residual."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 3000, 1500
+    J = synth.uniform_jacobian(n, m, 8, 21)
+    vi, ci, _ = synth.working_set_all_rows(n, m, 0.0, 21)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    b = np.random.default_rng(4).standard_normal(N)
+    fact.set_option("refine_steps", 0)
+    outs = []
+    for wide in (0, 300):
+        fact.set_option("wide_min_rows", wide)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("max_r") >= 700  # the Schur complement of this family is (nearly) dense
+        for _ in range(2):
+            fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+        assert fact.info("solve_timeouts") == 0
+        assert scaled_residual(K, outs[-1], b) <= 1e-10
+    assert rel_err(outs[1], outs[0]) <= 1e-10
+
+
 def test_top_of_tree_solve_variants_agree_bitwise(fact):
     """Level-by-level solve launches, the single-launch top-of-tree kernels, and their
     panel-prefetching variant run the same arithmetic in the same order: identical bits."""
