@@ -1804,7 +1804,8 @@ __device__ __forceinline__ void dev_fwd_wide_head(const TopItem& T, const double
 // lds: w | WIDE_SLICE_ROWS | 1024
 __device__ __forceinline__ void dev_fwd_wide_slice(const TopItem& T, const double* __restrict__ L,
                                                    const int* __restrict__ inv, const double* __restrict__ y,
-                                                   double* __restrict__ uvec, double* lds) {
+                                                   double* __restrict__ uvec, double* lds, int* __restrict__ hflags,
+                                                   int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r;
   const int us = T.a1 - T.a0;  // <= WIDE_SLICE_ROWS
@@ -1812,36 +1813,39 @@ __device__ __forceinline__ void dev_fwd_wide_slice(const TopItem& T, const doubl
   double* xs = lds;
   double* fb = xs + w;
   double* part = fb + WIDE_SLICE_ROWS;
-  for (int k = tid; k < w; k += SB) xs[k] = y[T.c0 + k];
+  // 64-row chunks x column slices; this thread's <= 32 entries of L21 and the children's
+  // entries are requested before the head of the front is awaited
+  const int nchunk = (us + 63) >> 6;  // <= 4
+  const int nslice = 16 / nchunk;
+  const int ch = wave % nchunk, sl = wave / nchunk;
+  const int pa = (ch << 6) + lane;
+  const int lo = (int)(((long long)w * sl) / nslice), hi = (int)(((long long)w * (sl + 1)) / nslice);
+  double lv[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) lv[j] = (sl < nslice && pa < us && lo + j < hi) ? P[pa + (long long)(lo + j) * r] : 0.0;
   for (int a = tid; a < us; a += SB) {
     double s = 0.0;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < T.nchild) {
-        const int ia = inv[T.c_invoff[ch] + w + T.a0 + a];
-        if (ia >= 0) s += uvec[T.c_uoff[ch] + ia];
+    for (int c2 = 0; c2 < MAXCH; ++c2)
+      if (c2 < T.nchild) {
+        const int ia = inv[T.c_invoff[c2] + w + T.a0 + a];
+        if (ia >= 0) s += uvec[T.c_uoff[c2] + ia];
       }
     fb[a] = s;
   }
+  top_wait(hflags, T.s, info, 1);
+  for (int k = tid; k < w; k += SB) xs[k] = y[T.c0 + k];
   __syncthreads();
-  // 64-row chunks x column slices, fixed-order reduction (as dev_fwd_front)
-  const int nchunk = (us + 63) >> 6;           // <= 4
-  const int nslice = 16 / nchunk;
-  const int ch = wave % nchunk, sl = wave / nchunk;
   if (sl < nslice) {
-    const int a = (ch << 6) + lane;
-    const int lo = (int)(((long long)w * sl) / nslice), hi = (int)(((long long)w * (sl + 1)) / nslice);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (a < us) {
-      const double* Lr = P + a;
-      int k = lo;
-      for (; k + 3 < hi; k += 4) {
-        s0 += Lr[(long long)k * r] * xs[k];
-        s1 += Lr[(long long)(k + 1) * r] * xs[k + 1];
-        s2 += Lr[(long long)(k + 2) * r] * xs[k + 2];
-        s3 += Lr[(long long)(k + 3) * r] * xs[k + 3];
-      }
-      for (; k < hi; ++k) s0 += Lr[(long long)k * r] * xs[k];
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+      // (entries beyond the slice are zero)
+      const int k = lo + j;
+      s0 += lv[j] * xs[min(k, w - 1)];
+      s1 += lv[j + 1] * xs[min(k + 1, w - 1)];
+      s2 += lv[j + 2] * xs[min(k + 2, w - 1)];
+      s3 += lv[j + 3] * xs[min(k + 3, w - 1)];
     }
     part[sl * (nchunk << 6) + (ch << 6) + lane] = (s0 + s1) + (s2 + s3);
   }
@@ -1857,29 +1861,42 @@ __device__ __forceinline__ void dev_fwd_wide_slice(const TopItem& T, const doubl
 // lds: WIDE_SLICE_ROWS
 __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const double* __restrict__ L,
                                                    const int* __restrict__ rows, const double* __restrict__ y,
-                                                   double* __restrict__ wpart, double* lds) {
+                                                   double* __restrict__ wpart, double* lds, int* __restrict__ flags,
+                                                   int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r;
   const int us = T.a1 - T.a0;
   const double* __restrict__ P = L + T.Loff + w + T.a0;
   const int* __restrict__ rw = rows + T.rowoff + w + T.a0;
   double* g = lds;
-  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) g[a] = (a < us) ? y[rw[a]] : 0.0;
-  __syncthreads();
-  // wave: 8 columns, lanes: rows lane + 64 q; shuffle tree per column (fixed order)
-  double s[8];
+  int* rwb = reinterpret_cast<int*>(g + WIDE_SLICE_ROWS);
+  // wave: 8 columns, lanes: rows lane + 64 q.  The slice of L21 (32 entries per thread) and the row
+  // list are requested before the parent is awaited.
+  double lv[8][WIDE_SLICE_ROWS / 64];
 #pragma unroll
   for (int cc = 0; cc < 8; ++cc) {
     const int k = 8 * wave + cc;
-    s[cc] = 0.0;
-    if (k < w) {
-      const double* col = P + (long long)k * r;
+    const double* col = P + (long long)k * r;
 #pragma unroll
-      for (int q = 0; q < WIDE_SLICE_ROWS / 64; ++q) {
-        const int a = lane + 64 * q;
-        if (a < us) s[cc] += col[a] * g[a];
-      }
+    for (int q = 0; q < WIDE_SLICE_ROWS / 64; ++q) {
+      const int a = lane + 64 * q;
+      lv[cc][q] = (k < w && a < us) ? col[a] : 0.0;
     }
+  }
+  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) rwb[a] = (a < us) ? rw[a] : -1;
+  if (T.parent >= 0)
+    top_wait(flags, T.parent, info, 1);
+  else
+    __syncthreads();
+  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) g[a] = (rwb[a] >= 0) ? y[rwb[a]] : 0.0;
+  __syncthreads();
+  // shuffle tree per column (fixed order)
+  double s[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    s[cc] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WIDE_SLICE_ROWS / 64; ++q) s[cc] += lv[cc][q] * g[lane + 64 * q];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1947,8 +1964,7 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
       dev_fwd_wide_head(T, L, rel, y, uvec, lds);
       top_publish(hflags, T.s);
     } else {
-      top_wait(hflags, T.s, info, 1);
-      dev_fwd_wide_slice(T, L, inv, y, uvec, lds);
+      dev_fwd_wide_slice(T, L, inv, y, uvec, lds, hflags, info);  // awaits the head after its prefetch
       top_publish_add(flags, T.s);
     }
     return;
@@ -1976,8 +1992,7 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
   // for one that has not been dispatched yet (no co-residency assumption for correctness)
   const TopItem& T = titems[gridDim.x - 1 - blockIdx.x];
   if (T.kind == 2) {
-    if (T.parent >= 0) top_wait(flags, T.parent, info, 1);
-    dev_bwd_wide_slice(T, L, rows, y, wpart, lds);
+    dev_bwd_wide_slice(T, L, rows, y, wpart, lds, flags, info);  // awaits the parent after its prefetch
     top_publish_add(hflags, T.s);
     return;
   }
