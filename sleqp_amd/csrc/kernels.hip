@@ -1916,15 +1916,36 @@ __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const doubl
 // lds: 2 w
 __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double* __restrict__ L,
                                                   double* __restrict__ y, const double* __restrict__ wpart,
-                                                  double* lds) {
+                                                  double* lds, int* __restrict__ flags, int* __restrict__ hflags,
+                                                  int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r;
   const double* __restrict__ P = L + T.Loff;
   double* v = lds;
+  double* zd = v + w;  // z_k / d_k
+  // requested before the slices (or the parent) are awaited: inv(L11) fragments, z / d
+  double xv[8][2];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int k = 8 * wave + cc;
+    const double* col = P + (long long)k * r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = k + 1 + lane + 64 * q;
+      xv[cc][q] = (k < w && t < w) ? col[t] : 0.0;
+    }
+  }
+  for (int k = tid; k < w; k += SB) zd[k] = y[T.c0 + k] / P[k + (long long)k * r];
+  if (T.nsl > 0)
+    top_wait(hflags, T.s, info, T.nsl);  // the slices waited for the parent
+  else if (T.parent >= 0)
+    top_wait(flags, T.parent, info, 1);
+  else
+    __syncthreads();
   for (int k = tid; k < w; k += SB) {
     double s = 0.0;
     for (int q = 0; q < T.nsl; ++q) s += wpart[T.poff + (long long)q * w + k];
-    v[k] = y[T.c0 + k] / P[k + (long long)k * r] - s;
+    v[k] = zd[k] - s;
   }
   __syncthreads();
   // x_k = v_k + inv(L11)(:,k)^T v below the diagonal: wave: 8 columns, lanes: rows k + 1 + lane + 64 q
@@ -1933,11 +1954,10 @@ __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double
     const int k = 8 * wave + cc;
     double s = 0.0;
     if (k < w) {
-      const double* col = P + (long long)k * r;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int t = k + 1 + lane + 64 * q;
-        if (t < w) s += col[t] * v[t];
+        if (t < w) s += xv[cc][q] * v[t];
       }
     }
 #pragma unroll
@@ -1997,11 +2017,7 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
     return;
   }
   if (T.kind == 1) {
-    if (T.nsl > 0)
-      top_wait(hflags, T.s, info, T.nsl);  // the slices waited for the parent
-    else if (T.parent >= 0)
-      top_wait(flags, T.parent, info, 1);
-    dev_bwd_wide_head(T, L, y, wpart, lds);
+    dev_bwd_wide_head(T, L, y, wpart, lds, flags, hflags, info);  // awaits its slices after its prefetch
     top_publish(flags, T.s);
     return;
   }
