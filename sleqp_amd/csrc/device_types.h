@@ -33,8 +33,9 @@ struct PullDesc {
   long long reloff[MAXCH];  // child's relative indices
   int invoff[MAXCH];        // child's inverse relative indices (SnDesc::pad1)
   int uc[MAXCH];            // order of the child's update matrix
-  int n;                    // number of children, -1 if more than MAXCH
-  int pad[3];
+  int n;                    // number of children in this block (<= MAXCH)
+  int next;                 // index of the block with the front's next children in the overflow array, -1: none
+  int pad[2];
 };
 
 // one workgroup of a split-phase kernel: everything it needs in ONE uniform load (a dependent

@@ -73,6 +73,7 @@ struct LevelInfo {
   // split mode (few, large fronts): one kernel per phase, many workgroups per front
   bool split = false;
   bool pull = false;  // split kernels gather the children's updates themselves (no phase A launch)
+  bool chain = false; // some front of the level has more than MAXCH children (descriptor chains)
   int nparts = 1;
   long long itA = 0;                    // offset (in ints) into d_items
   long long itB = 0, itC = 0, itD = 0;  // offsets (in FrontItems) into d_fitems
@@ -136,7 +137,7 @@ struct hipfact_handle {
   int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
-  int pull_max_children = 4;  // <= MAXCH; 0: always the separate assembly kernel
+  int pull_max_children = 4;  // 0: always the separate assembly kernel; otherwise pull for any number of children
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
   long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
@@ -147,7 +148,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags, d_ftarget, d_wpart;
+  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags, d_ftarget, d_wpart, d_pullx;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -274,22 +275,38 @@ static int upload_plan(hipfact_handle* h) {
       off += P.sn_r[p];
     }
   }
-  std::vector<PullDesc> pulls(ns);
+  // children of every front in blocks of MAXCH: the first block travels inside the work items, the
+  // others (fronts with more than MAXCH children) sit in an overflow array, chained by index
+  std::vector<PullDesc> pulls(ns), pullx;
   for (int s = 0; s < ns; ++s) {
-    PullDesc& pd = pulls[s];
-    memset(&pd, 0, sizeof(pd));
     const int nch = P.child_ptr[s + 1] - P.child_ptr[s];
-    pd.n = nch <= MAXCH ? nch : -1;
-    for (int k = 0; k < nch && nch <= MAXCH; ++k) {
+    PullDesc* cur = &pulls[s];
+    memset(cur, 0, sizeof(*cur));
+    cur->next = -1;
+    int last_x = -1;  // index of the block being filled inside pullx (-1: pulls[s])
+    for (int k = 0; k < nch; ++k) {
+      if (k > 0 && k % MAXCH == 0) {
+        PullDesc nb;
+        memset(&nb, 0, sizeof(nb));
+        nb.next = -1;
+        pullx.push_back(nb);
+        const int idx = (int)pullx.size() - 1;
+        (last_x < 0 ? pulls[s] : pullx[(size_t)last_x]).next = idx;
+        last_x = idx;
+      }
+      PullDesc& pd = last_x < 0 ? pulls[s] : pullx[(size_t)last_x];
       const int ch = P.child_idx[P.child_ptr[s] + k];
-      pd.Uoff[k] = sn[ch].Uoff;
-      pd.reloff[k] = sn[ch].reloff;
-      pd.invoff[k] = sn[ch].pad1;
-      pd.uc[k] = sn[ch].r - sn[ch].w;
+      const int q = k % MAXCH;
+      pd.Uoff[q] = sn[ch].Uoff;
+      pd.reloff[q] = sn[ch].reloff;
+      pd.invoff[q] = sn[ch].pad1;
+      pd.uc[q] = sn[ch].r - sn[ch].w;
+      pd.n = q + 1;
     }
   }
   int rc;
   if ((rc = upload(h, h->d_inv, inv))) return rc;
+  if ((rc = upload(h, h->d_pullx, pullx))) return rc;
   if ((rc = upload(h, h->d_sn, sn))) return rc;
   if ((rc = upload(h, h->d_level_sn, P.level_sn))) return rc;
   if ((rc = upload(h, h->d_rows, P.sn_rows))) return rc;
@@ -389,7 +406,8 @@ static int upload_plan(hipfact_handle* h) {
     max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
     // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
     li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5);
-    li.pull = li.split && mch > 0 && mch <= std::min(h->pull_max_children, MAXCH);
+    li.pull = li.split && mch > 0 && h->pull_max_children > 0;  // any number of children (descriptor chains)
+    li.chain = mch > MAXCH;
     {
       // assembly items: (front, target-column class) for every front that has children
       int with_children = 0;
@@ -484,7 +502,7 @@ static int upload_plan(hipfact_handle* h) {
       int mch = 0;
       for (int q = P.level_ptr[lvl - 1]; q < P.level_ptr[lvl]; ++q)
         mch = std::max(mch, P.child_ptr[P.level_sn[q] + 1] - P.child_ptr[P.level_sn[q]]);
-      if (!(li.count <= h->factor_top_max && mch <= std::min(h->pull_max_children, MAXCH))) break;
+      if (!(li.count <= h->factor_top_max && h->pull_max_children > 0 && mch <= MAXCH)) break;
       --lvl;
     }
     if (P.nlevels - lvl >= 2 && h->factor_top_max > 0) {
@@ -657,8 +675,9 @@ static int upload_plan(hipfact_handle* h) {
     h->error = "front too large for LDS-resident solve vectors";
     return HIPFACT_EINTERNAL;
   }
-  for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot), reinterpret_cast<const void*>(k_front_panel),
-                         reinterpret_cast<const void*>(k_front_schur), reinterpret_cast<const void*>(k_factor_top),
+  for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot<false>), reinterpret_cast<const void*>(k_front_pivot<true>),
+                         reinterpret_cast<const void*>(k_front_panel<false>), reinterpret_cast<const void*>(k_front_panel<true>),
+                         reinterpret_cast<const void*>(k_front_schur<false>), reinterpret_cast<const void*>(k_front_schur<true>), reinterpret_cast<const void*>(k_factor_top),
                          reinterpret_cast<const void*>(k_fwd_top),
                          reinterpret_cast<const void*>(k_bwd_top)})
     HCHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -733,14 +752,23 @@ static int factor_enqueue(hipfact_handle* h) {
              h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
     if (li.split && h->debug_phases == 15) {
       const FrontItem* fit = h->d_fitems.as<FrontItem>();
-      LAUNCH(PC_FACTOR_B, k_front_pivot, dim3(li.count), dim3(512), li.lds_pivot, fit + li.itB, h->d_L.as<double>(),
-             h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
-      if (li.nC > 0)
-        LAUNCH(PC_FACTOR_C, k_front_panel, dim3(li.nC), dim3(li.panel_threads), li.lds_panel, fit + li.itC,
-               h->d_L.as<double>(), h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
-      if (li.nD > 0)
-        LAUNCH(PC_FACTOR_D, k_front_schur, dim3(li.nD), dim3(FB), li.lds_schur, fit + li.itD, h->d_L.as<double>(),
-               h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), pull);
+#define SPLIT_LAUNCHES(CH)                                                                                              \
+  LAUNCH(PC_FACTOR_B, k_front_pivot<CH>, dim3(li.count), dim3(512), li.lds_pivot, fit + li.itB, h->d_L.as<double>(),   \
+         h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), h->d_pullx.as<PullDesc>(), \
+         pull);                                                                                                        \
+  if (li.nC > 0)                                                                                                       \
+    LAUNCH(PC_FACTOR_C, k_front_panel<CH>, dim3(li.nC), dim3(li.panel_threads), li.lds_panel, fit + li.itC,            \
+           h->d_L.as<double>(), h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(),                          \
+           h->d_pullx.as<PullDesc>(), pull);                                                                           \
+  if (li.nD > 0)                                                                                                       \
+    LAUNCH(PC_FACTOR_D, k_front_schur<CH>, dim3(li.nD), dim3(FB), li.lds_schur, fit + li.itD, h->d_L.as<double>(),     \
+           h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), h->d_pullx.as<PullDesc>(), pull);
+      if (li.chain) {
+        SPLIT_LAUNCHES(true)
+      } else {
+        SPLIT_LAUNCHES(false)
+      }
+#undef SPLIT_LAUNCHES
     } else {
       LAUNCH(PC_FACTOR, k_factor_level, dim3(li.count), dim3(FB), li.lds_factor, h->d_sn.as<SnDesc>(),
              h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(),

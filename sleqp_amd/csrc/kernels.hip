@@ -188,12 +188,14 @@ struct PullCtx {
   const int* inv[MAXCH];
   const int* rel[MAXCH];
   int uc[MAXCH];
+  int next;  // further children of the front: block index in the overflow array (fronts with > MAXCH children)
 };
 
 __device__ __forceinline__ PullCtx make_pull(const PullDesc& D, const double* __restrict__ U,
                                              const int* __restrict__ inv, const int* __restrict__ rel, int pull) {
   PullCtx pc;
   pc.n = pull ? D.n : 0;
+  pc.next = pull ? D.next : -1;
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch) {
     pc.Uc[ch] = nullptr;
@@ -376,6 +378,59 @@ __device__ __forceinline__ void dev_trailing_tile(const FrontCtx& c, int k0, int
 // Blocked right-looking LDL^T (nb = 16) with look-ahead: in the trailing update of
 // step kb, wave 0 updates the next diagonal tile first and factors it at once,
 // while the other waves finish the remaining tiles.  Any number of waves >= 1.
+// overflow blocks of children descriptors (fronts with more than MAXCH children) and what is needed to resolve them
+struct PullMore {
+  const PullDesc* more;
+  const double* U;
+  const int* inv;
+  const int* rel;
+};
+__device__ __forceinline__ PullMore no_more() { return PullMore{nullptr, nullptr, nullptr, nullptr}; }
+
+// pivot-block gathers of one block of children (maps of the pivot rows in LDS: invb), added in child order
+__device__ __forceinline__ void pivot_gather_stage1(const PullCtx& pc, const int* invb, int wp, int i1, int kq1,
+                                                    double (&v1)[4]) {
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n) {
+      const double* __restrict__ Uc = pc.Uc[ch];
+      const int uc = pc.uc[ch];
+      const int* ib = invb + ch * wp;
+      const int ci = (i1 < wp) ? ib[i1] : -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ck = ib[kq1 + 4 * q];
+        const bool ok = ci >= 0 && ck >= 0 && ci >= ck;
+        const double g = Uc[ok ? ci + (long long)ck * uc : 0];
+        v1[q] += ok ? g : 0.0;
+      }
+    }
+}
+__device__ __forceinline__ void pivot_gather_stage2(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
+                                                    double (&v)[2][16]) {
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < pc.n) {
+      const double* __restrict__ Uc = pc.Uc[ch];
+      const int uc = pc.uc[ch];
+      const int* ib = invb + ch * wp;
+      int ci[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = 15 + wave + 7 * q;
+        const int ck = (k < wp) ? ib[k] : -1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
+          const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
+          v[t][q] += ok ? g : 0.0;
+        }
+      }
+    }
+}
+
 // Dependencies of a workgroup of the single-launch top-of-tree factorisation (k_factor_top): the
 // Schur workgroups of the children must have finished before their update matrices are read.
 // n == 0 in the per-level kernels (the launch order is the dependency).
@@ -405,9 +460,9 @@ __device__ __forceinline__ ChildWait no_wait() {
 
 // ROWINV (8 waves): the inverse of the unit lower factor is formed block row by block row in
 // the shadow of the diagonal-block chain instead of by recursive doubling afterwards.
-template <bool ROWINV>
+template <bool ROWINV, bool CHAIN = false>
 __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc,
-                                                const ChildWait& cw) {
+                                                const ChildWait& cw, const PullMore pm = no_more()) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -450,59 +505,58 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       if (ch < pc.n && tid < wp) invb[ch * wp + tid] = iv[ch];
     __syncthreads();
     cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited
+    pivot_gather_stage1(pc, invb, wp, i1, kq1, v1);
+    if (!CHAIN || pc.next < 0) {
+      if (i1 < wp) {
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < pc.n) {
-        const double* __restrict__ Uc = pc.Uc[ch];
-        const int uc = pc.uc[ch];
-        const int* ib = invb + ch * wp;
-        const int ci = (i1 < wp) ? ib[i1] : -1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ck = ib[kq1 + 4 * q];
-          const bool ok = ci >= 0 && ck >= 0 && ci >= ck;
-          const double g = Uc[ok ? ci + (long long)ck * uc : 0];
-          v1[q] += ok ? g : 0.0;
-        }
+        for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
       }
-    if (i1 < wp) {
+      __syncthreads();
+      if (wave == 0) {
+        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);
+      } else {
+        pivot_gather_stage2(pc, invb, wp, lane, wave, v);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < MAXCH; ++ch)
-        if (ch < pc.n) {
-          const double* __restrict__ Uc = pc.Uc[ch];
-          const int uc = pc.uc[ch];
-          const int* ib = invb + ch * wp;
-          int ci[2];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const int k = 15 + wave + 7 * q;
-            const int ck = (k < wp) ? ib[k] : -1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
-              const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
-              v[t][q] += ok ? g : 0.0;
-            }
+            const int i = lane + 64 * t, k = 15 + wave + 7 * q;
+            if (i < wp && k < wp) A[i + k * lda] = v[t][q];
           }
-        }
+      }
+      __syncthreads();
+    } else {
+      // more than MAXCH children: block after block (child order), everything gathered before
+      // anything is stored; the first diagonal block does not overlap the gather here
+      if (wave >= 1) pivot_gather_stage2(pc, invb, wp, lane, wave, v);
+      for (int nx = pc.next; nx >= 0;) {
+        const PullCtx px = make_pull(pm.more[nx], pm.U, pm.inv, pm.rel, 1);
+        __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int ch = 0; ch < MAXCH; ++ch)
+          if (tid < wp) invb[ch * wp + tid] = (ch < px.n && tid < w) ? px.inv[ch][tid] : -1;
+        __syncthreads();
+        pivot_gather_stage1(px, invb, wp, i1, kq1, v1);
+        if (wave >= 1) pivot_gather_stage2(px, invb, wp, lane, wave, v);
+        nx = px.next;
+      }
+      if (i1 < wp) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int i = lane + 64 * t, k = 15 + wave + 7 * q;
-          if (i < wp && k < wp) A[i + k * lda] = v[t][q];
-        }
+        for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
+      }
+      if (wave >= 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int i = lane + 64 * t, k = 15 + wave + 7 * q;
+            if (i < wp && k < wp) A[i + k * lda] = v[t][q];
+          }
+      }
+      __syncthreads();
+      if (wave == 0 && !(phases & 32)) dev_diag_block(c, scratch, 0, info);
+      __syncthreads();
     }
-    __syncthreads();
   } else {
     // eight columns per batch so that the panel loads are in flight together
     for (int kk = wave; kk < wp; kk += 8 * nw)
@@ -876,10 +930,11 @@ __device__ __forceinline__ void schur_tile_gather(const PullCtx& pc, const int* 
     }
 }
 
-template <bool DD_IN_LDS>
+template <bool DD_IN_LDS, bool CHAIN = false>
 __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, double* SJ, int I, int J, bool assign,
                                                const PullCtx& pc, const int tid, int* wait_addr = nullptr,
-                                               int wait_target = 0, int* info = nullptr) {
+                                               int wait_target = 0, int* info = nullptr,
+                                               const PullMore pm = no_more()) {
   // wait_addr (single-launch top-of-tree factorisation): the children's entries are gathered
   // first, then the panel workgroups of the own front are awaited, then the operands are staged
   // tid: thread index inside the 256-thread team that owns the tile (barriers stay workgroup-wide)
@@ -987,8 +1042,28 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
       }
     }
   }
+  if (!wait_addr) {
+    if (!idle) schur_tile_gather(pc, invs, i0, j0, li, lk, uv);
+    // fronts with more than MAXCH children: further blocks of children, in child order
+    for (int nx = CHAIN ? pc.next : -1; nx >= 0;) {
+      const PullCtx px = make_pull(pm.more[nx], pm.U, pm.inv, pm.rel, 1);
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = (tid >> 7) + 2 * h, idx = tid & 127;
+        const int gi = (idx < 64) ? 64 * I + idx : 64 * J + idx - 64;
+        int val = -1;
+#pragma unroll
+        for (int cc = 0; cc < MAXCH; ++cc)
+          if (cc == ch && cc < px.n && gi < u && !ghost) val = px.inv[cc][w + gi];
+        invs[tid + 256 * h] = val;
+      }
+      __syncthreads();
+      if (!idle) schur_tile_gather(px, invs, i0, j0, li, lk, uv);
+      nx = px.next;
+    }
+  }
   if (idle) return;
-  if (!wait_addr) schur_tile_gather(pc, invs, i0, j0, li, lk, uv);
   // acc[x][y][q] = update of U(i = 64 I + i0 + 16 y + li, j = 64 J + j0 + 16 x + lk + 4 q)
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -1044,22 +1119,26 @@ __global__ __launch_bounds__(1024) void k_front_assemble(const SnDesc* __restric
   dev_assemble(S, c, sn, U, rel, child_idx, items[2 * blockIdx.x + 1], nparts, reinterpret_cast<int*>(lds));
 }
 
-// split kernels B / C / D: one self-contained FrontItem per workgroup
+// split kernels B / C / D: one self-contained FrontItem per workgroup.  CHAIN: the level has fronts
+// with more than MAXCH children (further descriptor blocks in `more`)
+template <bool CHAIN>
 __global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict__ items, double* __restrict__ L,
                                                     double* __restrict__ U, int* __restrict__ info,
                                                     const int* __restrict__ inv, const int* __restrict__ rel,
-                                                    int pull) {
+                                                    const PullDesc* __restrict__ more, int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
-  dev_pivot_block<true>(c, info, 15, pc, no_wait());  // stores the finished tiles itself
+  dev_pivot_block<true, CHAIN>(c, info, 15, pc, no_wait(), PullMore{more, U, inv, rel});  // stores the finished tiles itself
 }
 
 // LDS: dd | X | MAXCH x wp ints (the children's inverse maps of the pivot columns)
+template <bool CHAIN>
 __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict__ items, double* __restrict__ L,
                                                     double* __restrict__ U, const int* __restrict__ inv,
-                                                    const int* __restrict__ rel, int pull) {
+                                                    const int* __restrict__ rel, const PullDesc* __restrict__ more,
+                                                    int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
@@ -1071,23 +1150,41 @@ __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict
       for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
   // this wave's 16 panel rows leave for the registers before X is staged: one round trip for both
   const int R0 = c.w + 16 * (blockDim.x >> 6) * S.part + 16 * (threadIdx.x >> 6);
+  const bool rok = (R0 + (int)(threadIdx.x & 15)) < c.r;
   double pv[8][4];
   int cis[MAXCH];
   dev_panel_rows_load(c, R0, pc, pv, cis);
   dev_load_pivot_block(c, true);
-  if (R0 < c.r) dev_panel_rows_finish<true>(c, R0, pc, invl, pv, cis);
+  dev_panel_rows_gather(c, pc, invl, pv, cis);
+  // fronts with more than MAXCH children: further blocks of children, in child order
+  for (int nx = CHAIN ? pc.next : -1; nx >= 0;) {
+    const PullCtx px = make_pull(more[nx], U, inv, rel, 1);
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (ch < px.n && k < c.w) ? px.inv[ch][k] : -1;
+      cis[ch] = (ch < px.n && rok) ? px.inv[ch][R0 + (threadIdx.x & 15)] : -1;
+    }
+    __syncthreads();
+    dev_panel_rows_gather(c, px, invl, pv, cis);
+    nx = px.next;
+  }
+  dev_panel_rows_product<true>(c, R0, pv);
 }
 
 // part = (I << 16) | J
+template <bool CHAIN>
 __global__ __launch_bounds__(FB, 3) void k_front_schur(const FrontItem* __restrict__ items, double* __restrict__ L,
                                                     double* __restrict__ U, const int* __restrict__ inv,
-                                                    const int* __restrict__ rel, int pull) {
+                                                    const int* __restrict__ rel, const PullDesc* __restrict__ more,
+                                                    int pull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
   const int ij = S.part;
-  dev_schur_tile<false>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x);
+  dev_schur_tile<false, CHAIN>(c, c.A, c.A + 64 * KC, ij >> 16, ij & 0xffff, S.nchild == 0, pc, threadIdx.x, nullptr, 0,
+                               nullptr, PullMore{more, U, inv, rel});
 }
 
 // ---------------------------------------------------------------------------

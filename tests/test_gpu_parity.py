@@ -442,6 +442,29 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
 
+def test_pull_with_more_children_than_one_descriptor_block(fact):
+    """Fronts with more than four children (amalgamation unconstrained): the gathers walk a chain of
+    descriptor blocks, in child order - identical bits to the scatter kernel."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 20000, 10000
+    J = synth.banded_jacobian(n, m, 12, 80, 13)
+    vi, ci, _ = synth.working_set_all_rows(n, m, 0.0, 13)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    b = np.random.default_rng(1).standard_normal(N)
+    fact.set_option("refine_steps", 0)
+    fact.set_option("max_children", 0)
+    outs = []
+    for pull in (0, 4):
+        fact.set_option("pull_max_children", pull)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        outs.append(fact.solution_raw(0, N))
+    assert np.array_equal(outs[0], outs[1])
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    assert scaled_residual(K, outs[0], b) <= 1e-9
+
+
 @pytest.mark.parametrize("workload", ["banded_n1e5_m5e4", "uniform_n1e4_m5e3"])
 def test_full_size_properties(fact, workload):
     """BASELINE.json configs[3] / configs[2] at full size: properties that do not need the dense oracle."""
