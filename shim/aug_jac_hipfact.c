@@ -26,8 +26,13 @@
 
 #include "hipfact.h"
 
-typedef struct
+#include <pthread.h>
+
+typedef struct AugJacData
 {
+  struct AugJacData* next; /* registry of live instances (SleqpAugJac is opaque: no data accessor) */
+  SleqpAugJac* owner;
+
   SleqpProblem* problem;
   hipfact_handle* handle;
 
@@ -39,6 +44,26 @@ typedef struct
   int* cons_index; /* num_constraints */
   double* slice;   /* dense staging for hipfact_solution */
 } AugJacData;
+
+static pthread_mutex_t registry_lock = PTHREAD_MUTEX_INITIALIZER;
+static AugJacData* registry        = NULL;
+
+hipfact_handle*
+sleqp_hipfact_aug_jac_handle(SleqpAugJac* aug_jac)
+{
+  hipfact_handle* handle = NULL;
+  pthread_mutex_lock(&registry_lock);
+  for (AugJacData* it = registry; it; it = it->next)
+  {
+    if (it->owner == aug_jac)
+    {
+      handle = it->handle;
+      break;
+    }
+  }
+  pthread_mutex_unlock(&registry_lock);
+  return handle;
+}
 
 #define HIPFACT_CALL(data, x)                                                  \
   do                                                                           \
@@ -188,6 +213,17 @@ aug_jac_free(void* data)
 {
   AugJacData* jacobian = (AugJacData*)data;
 
+  pthread_mutex_lock(&registry_lock);
+  for (AugJacData** it = &registry; *it; it = &(*it)->next)
+  {
+    if (*it == jacobian)
+    {
+      *it = jacobian->next;
+      break;
+    }
+  }
+  pthread_mutex_unlock(&registry_lock);
+
   hipfact_free(&jacobian->handle);
 
   sleqp_free(&jacobian->slice);
@@ -243,6 +279,12 @@ sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSet
                                     .free              = aug_jac_free};
 
   SLEQP_CALL(sleqp_aug_jac_create(star, problem, &callbacks, jacobian));
+
+  jacobian->owner = *star;
+  pthread_mutex_lock(&registry_lock);
+  jacobian->next = registry;
+  registry       = jacobian;
+  pthread_mutex_unlock(&registry_lock);
 
   return SLEQP_OKAY;
 }

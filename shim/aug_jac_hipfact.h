@@ -13,4 +13,10 @@ SLEQP_WARNUNUSED
 SLEQP_RETCODE
 sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSettings* settings);
 
+/* The hipfact handle (device factorisation) behind an augmented Jacobian created above, NULL for any
+ * other SleqpAugJac: used by tr_hipfact.c, which runs the projected CG on the same handle. */
+struct hipfact_handle;
+struct hipfact_handle*
+sleqp_hipfact_aug_jac_handle(SleqpAugJac* aug_jac);
+
 #endif /* SLEQP_AUG_JAC_HIPFACT_H */

@@ -55,6 +55,8 @@ struct SleqpSettings
 {
   int refcount;
   double zero_eps;
+  double stat_tol;
+  int max_newton_iterations;
 };
 
 SLEQP_RETCODE
@@ -63,6 +65,8 @@ sleqp_settings_create(SleqpSettings** star)
   SLEQP_CALL(sleqp_malloc(star));
   (*star)->refcount = 1;
   (*star)->zero_eps = 1e-20;
+  (*star)->stat_tol = 1e-6;
+  (*star)->max_newton_iterations = 100;
   return SLEQP_OKAY;
 }
 
@@ -77,6 +81,27 @@ sleqp_settings_release(SleqpSettings** star)
 
 double
 sleqp_settings_zero_eps(const SleqpSettings* settings) { return settings ? settings->zero_eps : 1e-20; }
+
+SLEQP_RETCODE
+sleqp_settings_capture(SleqpSettings* settings)
+{
+  ++settings->refcount;
+  return SLEQP_OKAY;
+}
+
+double
+sleqp_settings_stat_tol(const SleqpSettings* settings) { return settings ? settings->stat_tol : 1e-6; }
+
+int
+sleqp_settings_max_newton_iterations(const SleqpSettings* settings) { return settings ? settings->max_newton_iterations : 100; }
+
+SLEQP_RETCODE
+sleqp_settings_set_newton(SleqpSettings* settings, double stat_tol, int max_newton_iterations)
+{
+  settings->stat_tol              = stat_tol;
+  settings->max_newton_iterations = max_newton_iterations;
+  return SLEQP_OKAY;
+}
 
 /* ---- vectors ---- */
 SLEQP_RETCODE
@@ -579,6 +604,52 @@ sleqp_aug_jac_release(SleqpAugJac** star)
       SLEQP_CALL(aj->callbacks.free(aj->data));
     SLEQP_CALL(sleqp_problem_release(&aj->problem));
     free(aj);
+  }
+  *star = NULL;
+  return SLEQP_OKAY;
+}
+
+/* ---- SleqpTRSolver dispatch (tr/tr_solver.c) ---- */
+struct SleqpTRSolver
+{
+  int refcount;
+  SleqpTRCallbacks callbacks;
+  void* data;
+};
+
+SLEQP_RETCODE
+sleqp_tr_solver_create(SleqpTRSolver** star, SleqpTRCallbacks* callbacks, void* solver_data)
+{
+  SLEQP_CALL(sleqp_malloc(star));
+  (*star)->refcount  = 1;
+  (*star)->callbacks = *callbacks;
+  (*star)->data      = solver_data;
+  return SLEQP_OKAY;
+}
+
+SLEQP_RETCODE
+sleqp_tr_solver_solve(SleqpTRSolver* solver, SleqpAugJac* jacobian, const SleqpVec* multipliers, const SleqpVec* gradient,
+                      SleqpVec* newton_step, double trust_radius, double* tr_dual)
+{
+  return solver->callbacks.solve(jacobian, multipliers, gradient, newton_step, trust_radius, tr_dual, SLEQP_NONE,
+                                 solver->data);
+}
+
+SLEQP_RETCODE
+sleqp_tr_solver_current_rayleigh(SleqpTRSolver* solver, double* min_rayleigh, double* max_rayleigh)
+{
+  return solver->callbacks.rayleigh(min_rayleigh, max_rayleigh, solver->data);
+}
+
+SLEQP_RETCODE
+sleqp_tr_solver_release(SleqpTRSolver** star)
+{
+  SleqpTRSolver* solver = *star;
+  if (solver && --solver->refcount == 0)
+  {
+    if (solver->callbacks.free)
+      SLEQP_CALL(solver->callbacks.free(&solver->data));
+    free(solver);
   }
   *star = NULL;
   return SLEQP_OKAY;

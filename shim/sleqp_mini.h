@@ -99,6 +99,14 @@ SLEQP_RETCODE
 sleqp_settings_release(SleqpSettings** star);
 double
 sleqp_settings_zero_eps(const SleqpSettings* settings); /* SLEQP_SETTINGS_REAL_ZERO_EPS, default 1e-20 */
+SLEQP_RETCODE
+sleqp_settings_capture(SleqpSettings* settings);
+double
+sleqp_settings_stat_tol(const SleqpSettings* settings); /* SLEQP_SETTINGS_REAL_STAT_TOL, default 1e-6 */
+int
+sleqp_settings_max_newton_iterations(const SleqpSettings* settings); /* SLEQP_SETTINGS_INT_MAX_NEWTON_ITERATIONS, default 100 */
+SLEQP_RETCODE
+sleqp_settings_set_newton(SleqpSettings* settings, double stat_tol, int max_newton_iterations); /* harness only */
 
 /* ---- sparse vector (public struct, sparse/pub_vec.h:16-25) ---- */
 typedef struct SleqpVec
@@ -298,6 +306,32 @@ SLEQP_WARNUNUSED SLEQP_RETCODE
 sleqp_aug_jac_condition(SleqpAugJac* aug_jac, bool* exact, double* condition);
 SLEQP_WARNUNUSED SLEQP_RETCODE
 sleqp_aug_jac_release(SleqpAugJac** star);
+
+/* ---- SleqpTRSolver (tr/tr_solver.h, tr/tr_types.h) ---- */
+typedef struct SleqpTRSolver SleqpTRSolver;
+
+typedef SLEQP_RETCODE (*SLEQP_TR_SOLVER_SOLVE)(SleqpAugJac* jacobian, const SleqpVec* multipliers,
+                                               const SleqpVec* gradient, SleqpVec* newton_step, double trust_radius,
+                                               double* tr_dual, double time_limit, void* solver_data);
+typedef SLEQP_RETCODE (*SLEQP_TR_SOLVER_RAYLEIGH)(double* min_rayleigh, double* max_rayleigh, void* solver_data);
+typedef SLEQP_RETCODE (*SLEQP_TR_SOLVER_FREE)(void** solver_data);
+
+typedef struct
+{
+  SLEQP_TR_SOLVER_SOLVE solve;
+  SLEQP_TR_SOLVER_RAYLEIGH rayleigh;
+  SLEQP_TR_SOLVER_FREE free;
+} SleqpTRCallbacks;
+
+SLEQP_WARNUNUSED SLEQP_RETCODE
+sleqp_tr_solver_create(SleqpTRSolver** star, SleqpTRCallbacks* callbacks, void* solver_data);
+SLEQP_WARNUNUSED SLEQP_RETCODE
+sleqp_tr_solver_solve(SleqpTRSolver* solver, SleqpAugJac* jacobian, const SleqpVec* multipliers,
+                      const SleqpVec* gradient, SleqpVec* newton_step, double trust_radius, double* tr_dual);
+SLEQP_WARNUNUSED SLEQP_RETCODE
+sleqp_tr_solver_current_rayleigh(SleqpTRSolver* solver, double* min_rayleigh, double* max_rayleigh);
+SLEQP_WARNUNUSED SLEQP_RETCODE
+sleqp_tr_solver_release(SleqpTRSolver** star);
 
 #ifdef __cplusplus
 }

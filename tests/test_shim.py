@@ -1,4 +1,4 @@
-"""The SLEQP-side shim (shim/fact_hipfact.c, shim/aug_jac_hipfact.c) built against the
+"""The SLEQP-side shim (shim/fact_hipfact.c, shim/aug_jac_hipfact.c, shim/tr_hipfact.c) built against the
 stand-alone harness: CPU — it loads and exports the reference's entry points; GPU —
 driving it exactly like standard_aug_jac.c / the reference tests do reproduces the
 golden vectors."""
@@ -38,6 +38,8 @@ def shim(hipfact_lib):
 
 def test_shim_exports_reference_entry_points(shim):
     for name in ["sleqp_fact_create_default", "sleqp_fact_hipfact_create", "sleqp_hipfact_aug_jac_create",
+                 "sleqp_hipfact_aug_jac_handle", "sleqp_hipfact_tr_solver_create", "sleqp_hipfact_tr_bind",
+                 "sleqp_hipfact_tr_set_hessian", "sleqp_tr_solver_solve", "sleqp_tr_solver_release",
                  "sleqp_fact_set_matrix", "sleqp_fact_solve", "sleqp_fact_solution", "sleqp_fact_cond",
                  "sleqp_fact_flags", "sleqp_fact_release"]:
         assert hasattr(shim, name), name
@@ -162,6 +164,83 @@ def test_aug_jac_shim_against_golden(shim, c):
     assert [b.contents.indices[k] for k in range(b.contents.nnz)] == list(c.b_idx)  # shift undone
     for v in (g, sol, dual, b):
         shim.sleqp_vec_free(C.byref(v))
+    assert shim.sleqp_aug_jac_release(C.byref(aug)) == 0
+    shim.sleqp_iterate_release(C.byref(iterate))
+    shim.sleqp_problem_release(C.byref(problem))
+    shim.sleqp_settings_release(C.byref(settings))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0.3, 1e3])
+def test_tr_solver_shim_against_oracle(shim, radius):
+    """SleqpTRCallbacks on the device (shim/tr_hipfact.c): sleqp_tr_solver_solve with the hipfact
+    augmented Jacobian reproduces steihaug_solver_solve (oracle restatement) — step, iteration
+    behaviour at the trust-region boundary and in the interior."""
+    import scipy.sparse as sp
+
+    import oracle
+    from sleqp_amd import synth
+
+    n, m = 300, 120
+    J = synth.uniform_jacobian(n, m, 4, 7)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.05, 7)
+    B = sp.random(n, n, density=0.02, random_state=3)
+    HL = sp.tril((B @ B.T + 0.5 * sp.eye(n)).tocsc(), format="csc")
+    HL.sort_indices()
+    g = np.random.default_rng(5).standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    want, _ = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius)
+
+    class Case:  # what _fill_jac reads
+        pass
+
+    c = Case()
+    c.n, c.jp, c.ji, c.jx = n, J.indptr, J.indices, J.data
+    settings, problem, iterate, aug = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    assert shim.sleqp_problem_create_mini(C.byref(problem), n, m) == 0
+    assert shim.sleqp_iterate_create_mini(C.byref(iterate), problem) == 0
+    _fill_jac(shim, shim.sleqp_iterate_cons_jac(iterate), c)
+    ws = C.c_void_p(shim.sleqp_iterate_working_set(iterate))
+    for j in np.argsort(np.where(vi >= 0, vi, 1 << 30)):
+        if vi[j] >= 0:
+            assert shim.sleqp_working_set_add_var(ws, int(j), 1) == 0
+    for i in np.argsort(np.where(ci >= 0, ci, 1 << 30)):
+        if ci[i] >= 0:
+            assert shim.sleqp_working_set_add_cons(ws, int(i), 1) == 0
+    assert shim.sleqp_hipfact_aug_jac_create(C.byref(aug), problem, settings) == 0, shim.sleqp_error_msg()
+    assert shim.sleqp_aug_jac_set_iterate(aug, iterate) == 0, shim.sleqp_error_msg()
+    shim.sleqp_hipfact_aug_jac_handle.restype = C.c_void_p
+    assert shim.sleqp_hipfact_aug_jac_handle(aug)
+
+    tr, ctl, H = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_hipfact_tr_solver_create(C.byref(tr), C.byref(ctl), problem, settings) == 0
+    assert shim.sleqp_hipfact_tr_bind(ctl, aug) == 0, shim.sleqp_error_msg()
+    assert shim.sleqp_mat_create(C.byref(H), n, n, max(HL.nnz, 1)) == 0
+    for j in range(n):
+        assert shim.sleqp_mat_push_col(H, j) == 0
+        for e in range(HL.indptr[j], HL.indptr[j + 1]):
+            assert shim.sleqp_mat_push(H, int(HL.indices[e]), j, C.c_double(float(HL.data[e]))) == 0
+    assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0, shim.sleqp_error_msg()
+    assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0  # same pattern: values-only path
+
+    grad = _vec(shim, n, np.arange(n), g)
+    mult = _vec(shim, m, [], [])
+    step = C.POINTER(SleqpVecC)()
+    assert shim.sleqp_vec_create_empty(C.byref(step), n) == 0
+    dual = C.c_double()
+    assert shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual)) == 0, \
+        shim.sleqp_error_msg()
+    got = _dense(step)
+    assert rel_err(got, want) <= 1e-8
+    assert np.linalg.norm(got) <= radius * (1 + 1e-10)
+    lo, hi = C.c_double(), C.c_double()
+    assert shim.sleqp_tr_solver_current_rayleigh(tr, C.byref(lo), C.byref(hi)) == 0
+
+    for v in (grad, mult, step):
+        shim.sleqp_vec_free(C.byref(v))
+    shim.sleqp_mat_release(C.byref(H))
+    assert shim.sleqp_tr_solver_release(C.byref(tr)) == 0 and not tr
     assert shim.sleqp_aug_jac_release(C.byref(aug)) == 0
     shim.sleqp_iterate_release(C.byref(iterate))
     shim.sleqp_problem_release(C.byref(problem))
