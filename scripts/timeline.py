@@ -1,0 +1,94 @@
+"""In-kernel timeline of the single-launch top-of-tree factorisation (wall_clock64 stamps).
+
+Builds an instrumented copy of the library (the product sources are patched in a scratch directory,
+never in place), runs the config-4 workload on the GPU and prints, for the workgroups on the
+critical path of the top levels, when they started, finished waiting, finished their work and
+published.  The numbers quoted in DESIGN.md section 4 come from this script
+(profiles/r1_timeline_factor_top.txt).
+
+    python scripts/timeline.py build     # here (hipcc cross-compiles)
+    python scripts/timeline.py run       # on the GPU box (gpurun)
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRATCH = os.path.join(ROOT, "sleqp_amd", "_timeline_build")  # sibling of csrc: same relative include paths
+SRC = os.path.join(ROOT, "sleqp_amd", "csrc")
+
+
+def build():
+    shutil.rmtree(SCRATCH, ignore_errors=True)
+    shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
+    p = os.path.join(SCRATCH, "kernels.hip")
+    s = open(p).read()
+    s = s.replace("typedef double d4_t __attribute__((ext_vector_type(4)));",
+                  "__device__ long long g_trace[4096 * 8];\n"
+                  "#define TRW(slot) if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + (slot)] = wall_clock64()\n"
+                  "typedef double d4_t __attribute__((ext_vector_type(4)));", 1)
+    a = s.index("__global__ __launch_bounds__(512) void k_factor_top(")
+    b = s.index("// titems: fronts of the levels >= top_level, children before parents")
+    seg = s[a:b]
+    seg = seg.replace("  ChildWait cw;\n  cw.n = T.nwait;",
+                      "  TRW(0);\n  if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 7] = T.role * 100000 + T.front;\n"
+                      "  ChildWait cw;\n  cw.n = T.nwait;", 1)
+    seg = seg.replace("    flag_publish_add(&bdone[T.front]);", "    TRW(2);\n    flag_publish_add(&bdone[T.front]);\n    TRW(3);", 1)
+    seg = seg.replace("    flag_wait_ge(&bdone[T.front], 1, info);", "    TRW(5);\n    flag_wait_ge(&bdone[T.front], 1, info);\n    TRW(1);", 1)
+    seg = seg.replace("    flag_publish_add(&cdone[T.front]);", "    TRW(2);\n    flag_publish_add(&cdone[T.front]);\n    TRW(3);", 1)
+    seg = seg.replace("    flag_publish_add(&ddone[T.front]);", "    TRW(2);\n    flag_publish_add(&ddone[T.front]);\n    TRW(3);", 1)
+    s = s[:a] + seg + s[b:]
+    s = s.replace("    cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited",
+                  "    if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
+                  "    cw.wait();\n"
+                  "    if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 1] = wall_clock64();", 1)
+    s = s.replace("    flag_wait_ge(wait_addr, wait_target, info);\n  }\n  const int si = tid & 63;",
+                  "    if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
+                  "    flag_wait_ge(wait_addr, wait_target, info);\n"
+                  "    if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 1] = wall_clock64();\n  }\n  const int si = tid & 63;", 1)
+    assert s.count("TRW(") >= 8
+    open(p, "w").write(s)
+    h = os.path.join(SCRATCH, "hipfact.hip")
+    t = open(h).read()
+    t += ('\nextern "C" int hipfact_debug_trace(long long* out) {\n'
+          "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * 4096 * 8);\n}\n")
+    open(h, "w").write(t)
+    subprocess.check_call(["make", "-C", SCRATCH])
+    print("built", os.path.join(SCRATCH, "libhipfact.so"))
+
+
+def run():
+    import numpy as np
+
+    os.environ["HIPFACT_LIBRARY"] = os.path.join(SCRATCH, "libhipfact.so")
+    sys.path.insert(0, ROOT)
+    from bench import make_problem
+    from sleqp_amd import _lib
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    f = HipFact(device=0)
+    f.set_option("use_graph", 0)
+    for _ in range(3):
+        f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    lib = _lib.load()
+    out = np.zeros(4096 * 8, dtype=np.int64)
+    lib.hipfact_debug_trace.argtypes = [C.c_void_p]
+    assert lib.hipfact_debug_trace(out.ctypes.data_as(C.c_void_p)) == 0
+    n = min(int(f.info("factor_top_count")), 4096)
+    t = out.reshape(4096, 8)[:n]
+    role, front = t[:, 7] // 100000, t[:, 7] % 100000
+    tt = (t[:, :6].astype(np.float64) - t[:, 0][t[:, 0] > 0].min()) / 100.0  # wall clock: 100 MHz
+    names = ["pivot", "panel", "schur"]
+    print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
+          "work done, published")
+    for i in range(max(0, n - 60), n):
+        print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {tt[i, 5]:8.2f}  waited {tt[i, 1]:8.2f}"
+              f"  done {tt[i, 2]:8.2f}  published {tt[i, 3]:8.2f}")
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "run"]()

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhipfact.so")
+# HIPFACT_LIBRARY: an alternative build of the same library (instrumented copies, scripts/timeline.py)
+LIB_PATH = os.environ.get("HIPFACT_LIBRARY") or os.path.join(_HERE, "csrc", "libhipfact.so")
 
 HIPFACT_OK = 0
 ERRORS = {

@@ -749,7 +749,26 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
   for (int k = tid; k < c.wp; k += blockDim.x) c.dd[k] = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
-  if (need_x)
+  if (need_x && nw == 8) {
+    // 8 waves, wp <= 128: the whole block as ONE batch of 2 x 16 loads per thread (each pass of the
+    // generic loop below is a dependent memory round trip on the critical path of the panel solve)
+    double v[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = lane + 64 * t, k = wave + 8 * q;
+        v[t][q] = (i == k) ? 1.0 : 0.0;
+        if (i < c.w && k < c.w && i > k) v[t][q] = c.P[i + (long long)k * c.r];
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = lane + 64 * t, k = wave + 8 * q;
+        if (i < c.wp && k < c.wp) c.A[i + k * c.lda] = v[t][q];
+      }
+  } else if (need_x)
     for (int kk = wave; kk < c.wp; kk += 8 * nw)
       for (int i = lane; i < c.wp; i += 64) {
         double v[8];
