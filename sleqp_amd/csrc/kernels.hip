@@ -745,10 +745,15 @@ __device__ __forceinline__ void dev_store_pivot_block(const FrontCtx& c) {
 }
 
 // reload inv(L11) and the pivots from a finished panel (split kernels)
-__device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool need_x) {
+// recip: dd receives 1 / d_k (the split panel kernels scale by multiplication: one division per
+// pivot and workgroup instead of one per entry of L21)
+__device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool need_x, bool recip = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
-  for (int k = tid; k < c.wp; k += blockDim.x) c.dd[k] = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
+  for (int k = tid; k < c.wp; k += blockDim.x) {
+    const double d = (k < c.w) ? c.P[k + (long long)k * c.r] : 1.0;
+    c.dd[k] = recip ? 1.0 / d : d;
+  }
   if (need_x && nw == 8) {
     // 8 waves, wp <= 128: the whole block as ONE batch of 2 x 16 loads per thread (each pass of the
     // generic loop below is a dependent memory round trip on the critical path of the panel solve)
@@ -842,7 +847,7 @@ __device__ __forceinline__ void dev_panel_rows_gather(const FrontCtx& c, const P
 // cstep / c0: this wave computes the 16-column output blocks ct == c0 (mod cstep) only (two waves
 // share a strip of rows in the top-of-tree launch, where workgroups are plentiful and the MFMA time
 // of a strip sits on the critical path)
-template <bool X_IN_LDS>
+template <bool X_IN_LDS, bool RECIP = false>
 __device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0, double (&pv)[8][4], int cstep = 1,
                                                        int c0 = 0) {
   const int lane = threadIdx.x & 63;
@@ -876,24 +881,24 @@ __device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0
           const int col = 16 * ct + lk + 4 * q;
           if (col < w) {
             const double dcol = X_IN_LDS ? c.dd[col] : P[col + (long long)col * r];
-            P[(R0 + li) + (long long)col * r] = acc[ct][q] / dcol;
+            P[(R0 + li) + (long long)col * r] = RECIP ? acc[ct][q] * dcol : acc[ct][q] / dcol;  // RECIP: dd holds 1 / d
           }
         }
       }
   }
 }
 
-template <bool X_IN_LDS>
+template <bool X_IN_LDS, bool RECIP = false>
 __device__ __forceinline__ void dev_panel_rows_finish(const FrontCtx& c, int R0, const PullCtx& pc, const int* invl,
                                                       double (&pv)[8][4], const int (&cis)[MAXCH]) {
   dev_panel_rows_gather(c, pc, invl, pv, cis);
-  dev_panel_rows_product<X_IN_LDS>(c, R0, pv);
+  dev_panel_rows_product<X_IN_LDS, RECIP>(c, R0, pv);
 }
 
 // ---- phase C: L21^T tiles = X P21^T, scaled by D^-1.  Each wave owns 16 panel
 // rows: the B operand streams from the panel (16 consecutive rows per k-step),
 // the A operand is X = inv(L11) in LDS.  Row blocks blk, blk + stride, ...
-template <bool X_IN_LDS>
+template <bool X_IN_LDS, bool RECIP = false>
 __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int blk_stride, const PullCtx& pc,
                                                 const int* invl) {
   const int wave = threadIdx.x >> 6;
@@ -902,7 +907,7 @@ __device__ __forceinline__ void dev_panel_solve(const FrontCtx& c, int blk, int 
     double pv[8][4];
     int cis[MAXCH];
     dev_panel_rows_load(c, R0, pc, pv, cis);
-    dev_panel_rows_finish<X_IN_LDS>(c, R0, pc, invl, pv, cis);
+    dev_panel_rows_finish<X_IN_LDS, RECIP>(c, R0, pc, invl, pv, cis);
   }
 }
 
@@ -1116,7 +1121,14 @@ __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ 
   dev_pivot_block<false>(c, info, phases, nopull, no_wait());
   dev_store_pivot_block(c);
   if (!(phases & 4)) return;
-  dev_panel_solve<true>(c, 0, 1, nopull, nullptr);
+  {
+    // scale by the reciprocal pivots like the split panel kernel (same bits): 1 / d_k into the free Y panel
+    for (int k = threadIdx.x; k < c.wp; k += blockDim.x) c.Yp[k] = 1.0 / c.dd[k];
+    __syncthreads();
+    FrontCtx cr = c;
+    cr.dd = c.Yp;
+    dev_panel_solve<true, true>(cr, 0, 1, nopull, nullptr);
+  }
   __syncthreads();
   if (c.u > 0 && (phases & 8)) {
     double* SI = c.A;
@@ -1173,7 +1185,7 @@ __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict
   double pv[8][4];
   int cis[MAXCH];
   dev_panel_rows_load(c, R0, pc, pv, cis);
-  dev_load_pivot_block(c, true);
+  dev_load_pivot_block(c, true, true);
   dev_panel_rows_gather(c, pc, invl, pv, cis);
   // fronts with more than MAXCH children: further blocks of children, in child order
   for (int nx = CHAIN ? pc.next : -1; nx >= 0;) {
@@ -1188,7 +1200,7 @@ __global__ __launch_bounds__(512) void k_front_panel(const FrontItem* __restrict
     dev_panel_rows_gather(c, px, invl, pv, cis);
     nx = px.next;
   }
-  dev_panel_rows_product<true>(c, R0, pv);
+  dev_panel_rows_product<true, true>(c, R0, pv);
 }
 
 // part = (I << 16) | J
@@ -1843,8 +1855,8 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     __syncthreads();
     dev_panel_rows_gather(c, pc, invl, pv, cis);
     flag_wait_ge(&bdone[T.front], 1, info);
-    dev_load_pivot_block(c, true);
-    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);
+    dev_load_pivot_block(c, true, true);
+    if (R0 < c.r) dev_panel_rows_product<true, true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);
     flag_publish_add(&cdone[T.front]);
   } else {
     // two 256-thread teams, one tile each (the same tile twice when the front has an odd number):
