@@ -50,12 +50,22 @@ def build():
                   "    if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
                   "    flag_wait_ge(wait_addr, wait_target, info);\n"
                   "    if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 1] = wall_clock64();\n  }\n  const int si = tid & 63;", 1)
+    # pivot role detail: after the children gather, after the first diagonal block, after every step
+    s = s.replace("__device__ long long g_trace[4096 * 8];", "__device__ long long g_trace[4096 * 8];\n__device__ long long g_piv[4096 * 24];\n"
+                  "#define TRP(slot) if (threadIdx.x == 0) g_piv[blockIdx.x * 24 + (slot)] = wall_clock64()", 1)
+    s = s.replace("      __syncthreads();\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n      } else {\n        pivot_gather_stage2(pc, invb, wp, lane, wave, v);",
+                  "      __syncthreads();\n      TRP(0);\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n        TRP(1);\n      } else {\n        pivot_gather_stage2(pc, invb, wp, lane, wave, v);", 1)
+    s = s.replace("    __syncthreads();\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", "    __syncthreads();\n    TRP(2 + 2 * kb);\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", 1)
+    s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n  }", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n    TRP(3 + 2 * kb);\n  }", 1)
+    assert s.count("TRP(") >= 5
     assert s.count("TRW(") >= 8
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "hipfact.hip")
     t = open(h).read()
     t += ('\nextern "C" int hipfact_debug_trace(long long* out) {\n'
-          "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * 4096 * 8);\n}\n")
+          "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * 4096 * 8);\n}\n"
+          'extern "C" int hipfact_debug_trace_pivot(long long* out) {\n'
+          "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_piv), sizeof(long long) * 4096 * 24);\n}\n")
     open(h, "w").write(t)
     subprocess.check_call(["make", "-C", SCRATCH])
     print("built", os.path.join(SCRATCH, "libhipfact.so"))
@@ -84,6 +94,10 @@ def run():
     t = out.reshape(4096, 8)[:n]
     role, front = t[:, 7] // 100000, t[:, 7] % 100000
     tt = (t[:, :6].astype(np.float64) - t[:, 0][t[:, 0] > 0].min()) / 100.0  # wall clock: 100 MHz
+    piv = np.zeros(4096 * 24, dtype=np.int64)
+    lib.hipfact_debug_trace_pivot.argtypes = [C.c_void_p]
+    assert lib.hipfact_debug_trace_pivot(piv.ctypes.data_as(C.c_void_p)) == 0
+    piv = piv.reshape(4096, 24)
     names = ["pivot", "panel", "schur"]
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
@@ -91,7 +105,13 @@ def run():
         extra = f"  inv(L11) staged {tt[i, 4]:8.2f}" if role[i] == 1 else ""
         print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {tt[i, 5]:8.2f}  waited {tt[i, 1]:8.2f}"
               f"  done {tt[i, 2]:8.2f}  published {tt[i, 3]:8.2f}{extra}")
+        if role[i] == 0 and i >= n - 16:
+            base = t[:, 0][t[:, 0] > 0].min()
+            st = [(x - base) / 100.0 for x in piv[i] if x > 0]
+            print("        pivot detail (gathered, first diagonal block, then per step: block column done, step done): "
+                  + " ".join(f"{x:.2f}" for x in st))
 
 
 if __name__ == "__main__":
     {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "run"]()
+
