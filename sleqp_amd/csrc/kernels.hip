@@ -406,28 +406,53 @@ __device__ __forceinline__ void pivot_gather_stage1(const PullCtx& pc, const int
       }
     }
 }
+// Stage 2 of the pivot-block load (waves 1..7): the lower triangle of the columns 16 .. wp-1 only.
+// Column 16 + p is folded with column wp - 1 - p, so that every pair holds wp - 15 entries: slot
+// (s, j) of a thread is entry t = lane + 64 s of pair p = (wave - 1) + 7 j.
+__device__ __forceinline__ bool stage2_elem(int wp, int wave, int lane, int s, int j, int& i, int& k) {
+  const int npairs = (wp - 16) >> 1;
+  const int p = (wave - 1) + 7 * j;
+  const int t = lane + 64 * s;
+  const int ka = 16 + p, kb = wp - 1 - p;
+  const int len1 = wp - ka;
+  const bool first = t < len1;
+  k = first ? ka : kb;
+  i = first ? ka + t : kb + (t - len1);
+  return wave >= 1 && p < npairs && t < wp - 15;
+}
 __device__ __forceinline__ void pivot_gather_stage2(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
-                                                    double (&v)[2][16]) {
+                                                    double (&v)[2][8]) {
+  // two children in flight at a time, added in child order
 #pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch)
-    if (ch < pc.n) {
-      const double* __restrict__ Uc = pc.Uc[ch];
-      const int uc = pc.uc[ch];
-      const int* ib = invb + ch * wp;
-      int ci[2];
+  for (int c0 = 0; c0 < MAXCH; c0 += 2)
+    if (c0 < pc.n) {
+      double g[2][2][8];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) ci[t] = (lane + 64 * t < wp) ? ib[lane + 64 * t] : -1;
+      for (int cc = 0; cc < 2; ++cc) {
+        const int ch = c0 + cc;
+        const bool has = ch < pc.n;
+        const double* __restrict__ Uc = has ? pc.Uc[ch] : pc.Uc[c0];
+        const int uc = has ? pc.uc[ch] : 0;
+        const int* ib = invb + (has ? ch : c0) * wp;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = 15 + wave + 7 * q;
-        const int ck = (k < wp) ? ib[k] : -1;
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bool ok = ci[t] >= 0 && ck >= 0 && ci[t] >= ck;
-          const double g = Uc[ok ? ci[t] + (long long)ck * uc : 0];
-          v[t][q] += ok ? g : 0.0;
-        }
+          for (int j = 0; j < 8; ++j) {
+            int i, k;
+            const bool valid = stage2_elem(wp, wave, lane, s2, j, i, k);
+            const int ci = (valid && has) ? ib[i] : -1;
+            const int ck = (valid && has) ? ib[k] : -1;
+            const bool ok = ci >= 0 && ck >= 0;  // i >= k by construction, rel is monotone
+            const double gv = Uc[ok ? ci + (long long)ck * uc : 0];
+            g[cc][s2][j] = ok ? gv : 0.0;
+          }
       }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[s2][j] += g[cc][s2][j];
     }
 }
 
@@ -491,14 +516,15 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       v1[q] = (i1 == k) ? 1.0 : 0.0;
       if (i1 < w && k < w) v1[q] = (i1 >= k) ? P[i1 + (long long)k * r] : 0.0;
     }
-    double v[2][16];  // stage 2 (waves 1..7): rows lane + 64 t, columns 16 + (wave - 1) + 7 q
+    double v[2][8];  // stage 2 (waves 1..7): lower triangle of the columns 16 .. wp-1, folded (stage2_elem)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int i = lane + 64 * t, k = 15 + wave + 7 * q;
-        v[t][q] = (i == k) ? 1.0 : 0.0;
-        if (wave >= 1 && i < w && k < w) v[t][q] = (i >= k) ? P[i + (long long)k * r] : 0.0;
+      for (int j = 0; j < 8; ++j) {
+        int i, k;
+        const bool valid = stage2_elem(wp, wave, lane, s2, j, i, k);
+        v[s2][j] = (valid && i == k) ? 1.0 : 0.0;
+        if (valid && i < w && k < w) v[s2][j] = P[i + (long long)k * r];
       }
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
@@ -517,11 +543,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       } else {
         pivot_gather_stage2(pc, invb, wp, lane, wave, v);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int i = lane + 64 * t, k = 15 + wave + 7 * q;
-            if (i < wp && k < wp) A[i + k * lda] = v[t][q];
+          for (int j = 0; j < 8; ++j) {
+            int i, k;
+            if (stage2_elem(wp, wave, lane, s2, j, i, k)) A[i + k * lda] = v[s2][j];
           }
       }
       __syncthreads();
@@ -546,11 +572,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       }
       if (wave >= 1) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int i = lane + 64 * t, k = 15 + wave + 7 * q;
-            if (i < wp && k < wp) A[i + k * lda] = v[t][q];
+          for (int j = 0; j < 8; ++j) {
+            int i, k;
+            if (stage2_elem(wp, wave, lane, s2, j, i, k)) A[i + k * lda] = v[s2][j];
           }
       }
       __syncthreads();
