@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--workload", default="banded_n1e5_m5e4")
     ap.add_argument("--refine", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the STREAM / DGEMM ceiling microbenchmarks")
     ap.add_argument("--solves-per-factor", type=int, default=1)
     args = ap.parse_args()
 
@@ -326,7 +327,7 @@ def main():
                                "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                                "flops_per_step": flops, "avg_launch_us": prof[dom]["avg_launch_us"],
                                "note": "all factor flops attributed to the Schur kernel (upper bound)"}
-        if world == 1:
+        if world == 1 and not args.no_ceilings:
             out["measured_ceilings"] = measured_ceilings(f"cuda:{local_rank}")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, cp, ri, vx, b)
