@@ -8,10 +8,13 @@
 // and the CSR SpMV replacing sleqp_mat_mult_vec / sleqp_mat_mult_vec_trans
 // (sparse/mat.c:282-363).
 //
-// Wave = 64 lanes; every block is 256 threads (4 waves, one per SIMD).  All
-// arithmetic is fp64.  The paths are HBM/L2-bound integer + fp64 streaming
-// work: coalesced column-major panel accesses, LDS for the dense diagonal
-// blocks and the Schur-update tiles.
+// Wave = 64 lanes; blocks are 256 (streaming kernels, Schur tiles), 512 (pivot / panel
+// workgroups, the dataflow factorisation) or 1024 threads (solves).  All arithmetic is fp64.
+// The numeric factorisation and the solves are bound by the critical path of the elimination
+// tree, so the code is organised around dependent memory round trips and issue slots rather
+// than bandwidth: self-contained work items, pull-mode extend-add, prefetch before every
+// dependency wait, and three single-launch dataflow kernels (k_factor_top, k_fwd_top,
+// k_bwd_top) in which workgroups synchronise through counters (DESIGN.md sections 2 and 4).
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -104,28 +107,32 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 // (v_mfma_f64_16x16x4_f64, verified lane layout: A[l&15][l>>4], B[l>>4][l&15],
 // D[(l>>4)+4q][l&15]).
 //
-//   A   zero the lower triangle of the update matrix U_s and extend-add the
-//       children's update matrices (relative indices).  Work is partitioned by
-//       TARGET column class (column mod nparts), so that several workgroups can
-//       assemble one front without write conflicts and in a fixed order.
+//   A   (scatter form, k_front_assemble: fused small-front levels and cross-check only) zero the
+//       lower triangle of the update matrix U_s and extend-add the children's update matrices
+//       (relative indices), partitioned by TARGET column class so that several workgroups can
+//       assemble one front without write conflicts and in a fixed order.  The split kernels
+//       below PULL instead: each gathers the children's entries of exactly what it is about to
+//       use (inverse relative indices, child order => same bits as the scatter form).
 //   B   blocked LDL^T (nb = 16) of the w x w pivot block in LDS:
-//         S1  16x16 diagonal block: LDL^T and its inverse in registers of one
-//             wave (cross-lane shuffles, no memory traffic)
+//         S1  16x16 diagonal block: LDL^T and its inverse in registers of one wave, one pass
+//             through the LDS crossbar per pivot (ds_bpermute / ds_swizzle), no LDS memory
 //         S2  block column  L_Ik = A_Ik inv(L_kk)^T D^-1          (MFMA)
-//         S3  trailing update A_IJ -= L_Ik D L_Jk^T                (MFMA)
-//       then the inverse of the unit lower factor by recursive doubling with
-//       MFMA products, so that the solves are pure GEMVs
+//         S3  trailing update A_IJ -= L_Ik D L_Jk^T                (MFMA), look-ahead: wave 0
+//             factors the next diagonal block meanwhile, and the other waves also form the
+//             inverse of the unit lower factor block row by block row (so that the solves are
+//             pure GEMVs) and store finished tiles
 //   C   L21 = P21 inv(L11)^T D^-1, panel rows streamed, X from LDS   (MFMA)
-//   D   U_s -= L21 D L21^T in 64 x 64 tiles, both operand strips staged in
-//       LDS (k-major), 32 x 32 block per wave                        (MFMA)
+//   D   U_s = sum(children) - L21 D L21^T in 64 x 64 tiles, operand strips staged in LDS
+//       (k-major, 32-pivot chunks), 32 x 32 block per wave           (MFMA)
 //
-// Levels with many fronts run the fused kernel (one workgroup per front, all
-// phases back to back); levels with few, large fronts run one kernel per phase
-// with many workgroups per front (k_front_assemble / _pivot / _panel / _schur).
+// Levels of tiny fronts run the fused kernel (one workgroup per front, phases B-D back to
+// back after a scatter assembly); wide levels run one kernel per phase with many workgroups per
+// front (k_front_pivot / _panel / _schur); the narrow top of the tree runs as ONE dataflow
+// launch (k_factor_top).
 //
 // LDS layout: dd[wp] | region.  Phase B: region = A (wp x lda, lda = wp + 1: row
 // fragments and transposed fragments are both <= 2-way bank conflicted) followed
-// by the 16-column panel Y.  Phase D: region = two w x 64 operand strips.
+// by the 16-column panel Y.  Phase D: region = two 64 x KC operand strips.
 // ---------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
