@@ -176,9 +176,27 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
 
 /* ---- options / introspection ------------------------------------------- */
 
-/* Options: "refine_steps" (iterative-refinement steps per solve, default 1),
- * "ordering" (0 nested dissection, 1 AMD, 2 natural), "wmax", "nd_leaf",
- * "force_generic", "use_graph", "pivot_tol". */
+/* Options.
+ *   numerics:  "refine_steps" (iterative-refinement steps per solve, default 1),
+ *              "refine_adaptive", "refine_tol";
+ *   analysis (take effect at the next set_matrix / assemble, which re-analyses):
+ *              "ordering" (0 nested dissection, 1 AMD, 2 natural), "wmax"
+ *              (widest supernode, default 128), "max_children" (amalgamation
+ *              keeps fronts at this many children, default 4), "nd_leaf",
+ *              "nd_sep_frac", "force_generic";
+ *   schedule (results are bit-identical for every setting; the parity tests
+ *   sweep them):
+ *              "use_graph" (replay the launch sequence as a hipGraph),
+ *              "factor_top_max" (levels with at most this many fronts are
+ *              factored inside the single dataflow launch, 0 = off),
+ *              "top_max_fronts" (same for the two solve launches),
+ *              "wide_min_rows" (fronts with at least this many update rows
+ *              are solved by several workgroups, 0 = off),
+ *              "pull_max_children" (0 = extend-add through the separate
+ *              assembly kernel), "top_prefetch", "split_max_fronts";
+ *   "profile" (1: event-time every kernel class, read back with
+ *              "prof_<class>_ms" / "prof_<class>_count"; -1 resets).
+ * Unknown names return HIPFACT_EINVAL. */
 int hipfact_set_option(hipfact_handle* h, const char* name, double value);
 
 /* Info: "N", "n", "m", "saddle", "nnzK", "nnzL", "nnzL_true", "flops",

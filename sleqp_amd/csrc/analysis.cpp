@@ -444,6 +444,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
       nd.leaf_size = prm.nd_leaf;
     else
       nd.leaf_size = 256;
+    if (const char* e = getenv("HIPFACT_ND_REFINE")) nd.refine = atoi(e) != 0;
     nd_order(g, nd, perm);
   }
   std::vector<int> iperm(m);

@@ -23,6 +23,11 @@ struct NDParams {
   int leaf_size = 200;        // stop dissecting below this many vertices
   double max_sep_frac = 0.20; // reject separators larger than this fraction of the subgraph
   double balance = 0.30;      // smaller side must hold at least this fraction
+  // FM-refined edge bisection + minimum vertex cover as a second separator candidate.  Off by
+  // default: on the band-like benchmark graphs it shrinks the separators by ~3 % but the resulting
+  // trees factor 1-5 % slower (HIPFACT_ND_REFINE=1 to try it on other graph classes).
+  bool refine = false;
+  double refine_balance = 0.42;  // the FM passes keep each side above this fraction
 };
 
 // nd_order: recursive level-structure nested dissection (separators last),

@@ -52,37 +52,62 @@ __device__ __forceinline__ void prod_pair(const int* __restrict__ prod_a, const 
   }
 }
 
+// One wave owns 64 consecutive entries and with them one contiguous range of the product list.
+// The lists are short on average (two products) but every column has a diagonal entry with one
+// product per nonzero of its row of A: a lane walking its own list serialises that many dependent
+// index -> value round trips while the other 63 lanes idle, and nearly every wave holds such a
+// lane.  So the wave loads its whole range cooperatively (coalesced index words, every gather
+// useful, 2 * MV_U independent loads in flight per lane), parks the factor pairs in LDS, and each
+// lane then sums its own products from there in list order (same fma chain, same bits).
+constexpr int MV_U = 4;
 template <class IDX, bool PACKED>
 __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __restrict__ prod_ptr,
                                                    const int* __restrict__ prod_a, const int* __restrict__ prod_b,
                                                    const IDX* __restrict__ target, const double* __restrict__ Kval,
                                                    double* __restrict__ L) {
-  for (long long e = blockIdx.x * (long long)FB + threadIdx.x; e < nM; e += (long long)gridDim.x * FB) {
-    const long long p0 = (long long)prod_ptr[e], p1 = (long long)prod_ptr[e + 1];
-    const long long tgt = (long long)target[e];
+  constexpr int CH = 64 * MV_U;
+  __shared__ double2 pairs[FB / 64][CH];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double2* buf = pairs[wv];
+  for (long long e0 = blockIdx.x * (long long)FB + wv * 64; e0 < nM; e0 += (long long)gridDim.x * FB) {
+    const long long e = e0 + lane;
+    const bool valid = e < nM;
+    const long long eend = (e0 + 64 < nM) ? e0 + 64 : nM;
+    const long long P0 = (long long)prod_ptr[e0], P1 = (long long)prod_ptr[eend];  // wave-uniform
+    const long long p0 = valid ? (long long)prod_ptr[e] : P1, p1 = valid ? (long long)prod_ptr[e + 1] : P1;
+    const long long tgt = valid ? (long long)target[e] : 0;
     double s = 0.0;
-    if (p1 > p0) {
-      // the first four products (most entries have at most two) as one batch of independent
-      // loads, clamped to the last valid one; the sum keeps the order of the list
-      int a[4], b[4];
-      double x[4], y[4];
+    for (long long c = P0; c < P1; c += CH) {
+      int a[MV_U], b[MV_U];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) prod_pair<PACKED>(prod_a, prod_b, (p0 + q < p1) ? p0 + q : p1 - 1, a[q], b[q]);
+      for (int u = 0; u < MV_U; ++u) {
+        const long long p = c + u * 64 + lane;
+        prod_pair<PACKED>(prod_a, prod_b, p < P1 ? p : P1 - 1, a[u], b[u]);
+        if (p >= P1) a[u] = b[u] = 0;  // unused slots share one cache line
+      }
+      double2 v[MV_U];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        x[q] = Kval[a[q]];
-        y[q] = Kval[b[q]];
+      for (int u = 0; u < MV_U; ++u) {
+        v[u].x = Kval[a[u]];
+        v[u].y = Kval[b[u]];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (p0 + q < p1) s = fma(x[q], y[q], s);
-      for (long long p = p0 + 4; p < p1; ++p) {
-        int pa, pb;
-        prod_pair<PACKED>(prod_a, prod_b, p, pa, pb);
-        s = fma(Kval[pa], Kval[pb], s);
+      for (int u = 0; u < MV_U; ++u) buf[u * 64 + lane] = v[u];
+      // LDS operations of one wave execute in order: no workgroup barrier, only keep the compiler
+      // from moving the reads above the writes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int lo = (int)((p0 > c ? p0 : c) - c);
+      const int hi = (int)((p1 < c + CH ? p1 : c + CH) - c);
+      for (int q = lo; q < hi; ++q) {
+        const double2 f = buf[q];
+        s = fma(f.x, f.y, s);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    L[tgt] = s;
+    if (valid) L[tgt] = s;
   }
 }
 

@@ -16,7 +16,10 @@
 #include <atomic>
 #include <cassert>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
+#include <queue>
 #include <thread>
 #include <vector>
 
@@ -341,6 +344,249 @@ struct NDState {
     for (int v : order) inset[v] = id;  // restore
   }
 
+  // ---- refined bisection --------------------------------------------------
+  // side / ext / deg are only valid for the vertices of the current subset.
+  std::vector<int8_t> side;
+  std::vector<int> ext, deg, lockst, mate, hk_dist;
+  int lock_stamp = 0;
+
+  void move_vertex(int v, int id) {
+    const int a = side[v];
+    side[v] = (int8_t)(1 - a);
+    ext[v] = deg[v] - ext[v];
+    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+      const int u = g.adj[q];
+      if (inset[u] != id) continue;
+      ext[u] += (side[u] == a) ? 1 : -1;
+    }
+  }
+
+  // One FM pass on the edge cut; returns the improvement (>= 0).
+  long long fm_pass(const std::vector<int>& verts, int id, int (&cnt)[2], int min_side) {
+    struct Ent {
+      int gain, v;
+      bool operator<(const Ent& o) const { return gain < o.gain || (gain == o.gain && v > o.v); }
+    };
+    std::priority_queue<Ent> heap[2];
+    const int ls = ++lock_stamp;
+    for (int v : verts)
+      if (ext[v] > 0) heap[side[v]].push({2 * ext[v] - deg[v], v});
+    std::vector<int> moved;
+    long long cur = 0, best = 0;
+    size_t best_len = 0;
+    const size_t limit = std::max<size_t>(64, verts.size() / 100);
+    auto top = [&](int s) -> bool {  // drop stale / locked entries
+      auto& h = heap[s];
+      while (!h.empty()) {
+        const Ent e = h.top();
+        if (lockst[e.v] == ls || side[e.v] != s || e.gain != 2 * ext[e.v] - deg[e.v])
+          h.pop();
+        else
+          return true;
+      }
+      return false;
+    };
+    while (moved.size() - best_len < limit) {
+      const bool ok0 = cnt[0] - 1 >= min_side && top(0);
+      const bool ok1 = cnt[1] - 1 >= min_side && top(1);
+      if (!ok0 && !ok1) break;
+      int s;
+      if (ok0 && ok1) {
+        const int g0 = heap[0].top().gain, g1 = heap[1].top().gain;
+        s = g0 != g1 ? (g0 > g1 ? 0 : 1) : (cnt[0] >= cnt[1] ? 0 : 1);
+      } else {
+        s = ok0 ? 0 : 1;
+      }
+      const Ent e = heap[s].top();
+      heap[s].pop();
+      const int v = e.v;
+      lockst[v] = ls;
+      cur += e.gain;
+      move_vertex(v, id);
+      --cnt[s];
+      ++cnt[1 - s];
+      moved.push_back(v);
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+        const int u = g.adj[q];
+        if (inset[u] != id || lockst[u] == ls) continue;
+        if (ext[u] > 0) heap[side[u]].push({2 * ext[u] - deg[u], u});
+      }
+      if (cur > best) {
+        best = cur;
+        best_len = moved.size();
+      }
+    }
+    for (size_t t = moved.size(); t > best_len; --t) {
+      const int v = moved[t - 1];
+      const int s = side[v];
+      move_vertex(v, id);
+      --cnt[s];
+      ++cnt[1 - s];
+    }
+    return best;
+  }
+
+  // Hopcroft-Karp on the bipartite graph of the cut edges (X: side 0, Y: side 1), then the
+  // Koenig cover: the smallest vertex set meeting every cut edge, i.e. a vertex separator.
+  void min_cover(const std::vector<int>& X, int id, std::vector<char>& in_cover) {
+    // mate[] / hk_dist[] are indexed by global vertex; only boundary vertices are touched
+    const int INF = 1 << 30;
+    std::vector<int> queue;
+    auto cross = [&](int v, int u) { return inset[u] == id && side[u] != side[v]; };
+    for (;;) {
+      queue.clear();
+      for (int x : X) {
+        if (mate[x] < 0) {
+          hk_dist[x] = 0;
+          queue.push_back(x);
+        } else {
+          hk_dist[x] = INF;
+        }
+      }
+      bool found = false;
+      for (size_t h = 0; h < queue.size(); ++h) {
+        const int x = queue[h];
+        for (int64_t q = g.ptr[x]; q < g.ptr[x + 1]; ++q) {
+          const int y = g.adj[q];
+          if (!cross(x, y)) continue;
+          const int x2 = mate[y];
+          if (x2 < 0) {
+            found = true;
+          } else if (hk_dist[x2] == INF) {
+            hk_dist[x2] = hk_dist[x] + 1;
+            queue.push_back(x2);
+          }
+        }
+      }
+      if (!found) break;
+      // layered DFS (iterative) from every free x
+      struct Fr {
+        int x;
+        int64_t q;
+      };
+      std::vector<Fr> st;
+      for (int x0 : X) {
+        if (mate[x0] >= 0) continue;
+        st.clear();
+        st.push_back({x0, g.ptr[x0]});
+        while (!st.empty()) {
+          Fr& f = st.back();
+          const int x = f.x;
+          bool advanced = false;
+          while (f.q < g.ptr[x + 1]) {
+            const int y = g.adj[f.q++];
+            if (!cross(x, y)) continue;
+            const int x2 = mate[y];
+            if (x2 < 0) {
+              // augment along the stack
+              int yy = y;
+              for (size_t t = st.size(); t > 0; --t) {
+                const int xx = st[t - 1].x;
+                const int prev = mate[xx];
+                mate[xx] = yy;
+                mate[yy] = xx;
+                yy = prev;
+              }
+              st.clear();
+              advanced = true;
+              break;
+            }
+            if (hk_dist[x2] == hk_dist[x] + 1) {
+              st.push_back({x2, g.ptr[x2]});
+              advanced = true;
+              break;
+            }
+          }
+          if (!advanced) {
+            hk_dist[x] = INF;  // dead end
+            st.pop_back();
+          }
+        }
+      }
+    }
+    // Koenig: Z = reachable from free X by alternating paths; cover = (X \ Z) + (Y & Z)
+    queue.clear();
+    for (int x : X) {
+      hk_dist[x] = 0;
+      if (mate[x] < 0) {
+        hk_dist[x] = 1;
+        queue.push_back(x);
+      }
+    }
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const int x = queue[h];
+      for (int64_t q = g.ptr[x]; q < g.ptr[x + 1]; ++q) {
+        const int y = g.adj[q];
+        if (!cross(x, y) || in_cover[y]) continue;
+        in_cover[y] = 1;  // y in Z
+        const int x2 = mate[y];
+        if (x2 >= 0 && !hk_dist[x2]) {
+          hk_dist[x2] = 1;
+          queue.push_back(x2);
+        }
+      }
+    }
+    for (int x : X)
+      if (!hk_dist[x]) in_cover[x] = 1;
+  }
+
+  std::vector<char> in_cover;
+
+  bool refined_cut(const std::vector<int>& order, int id, std::vector<int>& left, std::vector<int>& right,
+                   std::vector<int>& sep) {
+    const int k = (int)order.size();
+    if (side.empty()) {
+      side.assign(g.n, 0);
+      ext.assign(g.n, 0);
+      deg.assign(g.n, 0);
+      lockst.assign(g.n, 0);
+      mate.assign(g.n, -1);
+      hk_dist.assign(g.n, 0);
+      in_cover.assign(g.n, 0);
+    }
+    int cnt[2] = {k / 2, k - k / 2};
+    for (int t = 0; t < k; ++t) side[order[t]] = (int8_t)(t >= cnt[0]);
+    for (int v : order) {
+      int d = 0, e = 0;
+      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+        const int u = g.adj[q];
+        if (inset[u] != id) continue;
+        ++d;
+        e += side[u] != side[v];
+      }
+      deg[v] = d;
+      ext[v] = e;
+    }
+    const int min_side = std::max(1, (int)(prm.refine_balance * k));
+    for (int pass = 0; pass < 12; ++pass)
+      if (fm_pass(order, id, cnt, min_side) <= 0) break;
+    // boundary and cover
+    std::vector<int> X, B;
+    for (int v : order)
+      if (ext[v] > 0) {
+        B.push_back(v);
+        if (side[v] == 0) X.push_back(v);
+      }
+    if (X.empty()) return false;
+    for (int v : B) {
+      mate[v] = -1;
+      in_cover[v] = 0;
+    }
+    min_cover(X, id, in_cover);
+    for (int v : order) {
+      if (ext[v] > 0 && in_cover[v])
+        sep.push_back(v);
+      else
+        (side[v] == 0 ? left : right).push_back(v);
+    }
+    for (int v : B) {
+      mate[v] = -1;
+      in_cover[v] = 0;
+    }
+    const int small = (int)std::min(left.size(), right.size());
+    return small >= prm.balance * k;
+  }
+
   void rec(std::vector<int> verts) {
     const int k = (int)verts.size();
     if (k <= prm.leaf_size) {
@@ -421,47 +667,61 @@ struct NDState {
       return;
     }
 
-    // ---- choose the separator level: smallest level set among balanced cuts
-    int best_l = -1;
-    double best_cost = 1e300;
-    for (int l = 1; l + 1 < nlev; ++l) {
-      const int before = lev_ptr[l];
-      const int sz = lev_ptr[l + 1] - lev_ptr[l];
-      const int after = k - before - sz;
-      const int small = std::min(before, after);
-      if (small < prm.balance * k) continue;
-      const double cost = (double)sz * (1.0 + 0.5 * std::abs(before - after) / (double)k);
-      if (cost < best_cost) {
-        best_cost = cost;
-        best_l = l;
+    // ---- candidate 1: smallest level set among balanced cuts, trimmed
+    std::vector<int> left, right, sep;
+    {
+      int best_l = -1;
+      double best_cost = 1e300;
+      for (int l = 1; l + 1 < nlev; ++l) {
+        const int before = lev_ptr[l];
+        const int sz = lev_ptr[l + 1] - lev_ptr[l];
+        const int after = k - before - sz;
+        const int small = std::min(before, after);
+        if (small < prm.balance * k) continue;
+        const double cost = (double)sz * (1.0 + 0.5 * std::abs(before - after) / (double)k);
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_l = l;
+        }
+      }
+      if (best_l >= 0) {
+        left.assign(order.begin(), order.begin() + lev_ptr[best_l]);
+        right.assign(order.begin() + lev_ptr[best_l + 1], order.end());
+        // trim: separator vertices without a neighbour in the next level go left
+        for (int t = lev_ptr[best_l]; t < lev_ptr[best_l + 1]; ++t) {
+          const int v = order[t];
+          bool touches = false;
+          for (int64_t q = g.ptr[v]; q < g.ptr[v + 1] && !touches; ++q) {
+            const int u = g.adj[q];
+            touches = (inset[u] == id && level[u] == best_l + 1);
+          }
+          if (touches)
+            sep.push_back(v);
+          else
+            left.push_back(v);
+        }
       }
     }
-    if (best_l < 0) {
-      leaf(verts);
-      return;
-    }
-    const int sep_sz = lev_ptr[best_l + 1] - lev_ptr[best_l];
-    if (sep_sz > prm.max_sep_frac * k) {
-      leaf(verts);
-      return;
-    }
-
-    std::vector<int> left(order.begin(), order.begin() + lev_ptr[best_l]);
-    std::vector<int> right(order.begin() + lev_ptr[best_l + 1], order.end());
-    std::vector<int> sep;
-    sep.reserve(sep_sz);
-    // trim: separator vertices without a neighbour in the next level go left
-    for (int t = lev_ptr[best_l]; t < lev_ptr[best_l + 1]; ++t) {
-      const int v = order[t];
-      bool touches = false;
-      for (int64_t q = g.ptr[v]; q < g.ptr[v + 1] && !touches; ++q) {
-        const int u = g.adj[q];
-        touches = (inset[u] == id && level[u] == best_l + 1);
+    // ---- candidate 2: edge bisection of the BFS order refined by FM, then a minimum vertex
+    // cover of the cut edges.  Level sets of graphs with long-range edges (band-like M = A A^T)
+    // are smeared over about twice the width of the thinnest separator.
+    // (only where the level structure found a cut: otherwise the subgraph is small or has no
+    // thin separator, and another tree level costs more than it saves)
+    if (prm.refine && !sep.empty()) {
+      std::vector<int> l2, r2, s2;
+      const bool okr = refined_cut(order, id, l2, r2, s2);
+      if (getenv("HIPFACT_ND_DEBUG"))
+        fprintf(stderr, "nd k=%d levelset sep %zu (l %zu r %zu) refined ok %d sep %zu (l %zu r %zu)\n", k, sep.size(),
+                left.size(), right.size(), (int)okr, s2.size(), l2.size(), r2.size());
+      if (okr && s2.size() < sep.size()) {
+        left.swap(l2);
+        right.swap(r2);
+        sep.swap(s2);
       }
-      if (touches)
-        sep.push_back(v);
-      else
-        left.push_back(v);
+    }
+    if (sep.empty() || left.empty() || right.empty() || (double)sep.size() > prm.max_sep_frac * k) {
+      leaf(verts);
+      return;
     }
     std::vector<int>().swap(verts);
     std::vector<int>().swap(order);
