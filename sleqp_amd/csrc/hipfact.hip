@@ -148,7 +148,7 @@ struct hipfact_handle {
   Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
-  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_fflags, d_ftarget, d_wpart, d_pullx;
+  DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_ftarget, d_wpart, d_pullx;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
@@ -569,7 +569,6 @@ static int upload_plan(hipfact_handle* h) {
       h->ftop_count = (int)tf.size();
       h->ftop_lds = lds;
       if ((rc = upload(h, h->d_tfitems, tf))) return rc;
-      HCHECK(h, h->d_fflags.ensure(std::max<size_t>((size_t)3 * ns * sizeof(int), 16)));
     }
   }
   {
@@ -669,7 +668,8 @@ static int upload_plan(hipfact_handle* h) {
       if ((rc = upload(h, h->d_top_sn, top))) return rc;
       if ((rc = upload(h, h->d_titems, titems))) return rc;
     }
-    HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)2 * ns * sizeof(int), 16)));
+    HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)4 * ns * sizeof(int), 16)));
+    HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * ns * sizeof(int), h->stream));
   }
   if (max_lds > 160 * 1024) {
     h->error = "front too large for LDS-resident solve vectors";
@@ -689,7 +689,7 @@ static int upload_plan(hipfact_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // numeric workspaces
   HCHECK(h, h->d_Kval.ensure(std::max<size_t>((size_t)P.nnzK * sizeof(double), 16)));
-  HCHECK(h, h->d_L.ensure(std::max<size_t>((size_t)P.L_size * sizeof(double), 16)));
+  HCHECK(h, h->d_L.ensure((size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int) + 16));
   HCHECK(h, h->d_U.ensure(std::max<size_t>((size_t)P.U_size * sizeof(double), 16)));
   HCHECK(h, h->d_uvec.ensure(std::max<size_t>((size_t)P.u_size * sizeof(double), 16)));
   HCHECK(h, h->d_y.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
@@ -713,7 +713,8 @@ static int factor_enqueue(hipfact_handle* h) {
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_WORDS * sizeof(int), st));
   if (P.L_size > 0) {
     prof_begin(h, PC_MEMSET);
-    HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double), st));
+    // the dependency counters of k_factor_top live behind the arena: one fill clears both
+    HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int), st));
     prof_end(h);
   }
   const long long nM = (long long)P.Mi.size();
@@ -776,8 +777,7 @@ static int factor_enqueue(hipfact_handle* h) {
     }
   }
   if (lsplit < P.nlevels) {
-    int* fl = h->d_fflags.as<int>();
-    (void)hipMemsetAsync(fl, 0, (size_t)3 * P.nsuper * sizeof(int), h->stream);
+    int* fl = reinterpret_cast<int*>(h->d_L.as<double>() + P.L_size);  // cleared with the L arena
     LAUNCH(PC_FACTOR_T, k_factor_top, dim3(h->ftop_count), dim3(512), h->ftop_lds, h->d_tfitems.as<TopFItem>(),
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
            fl + P.nsuper, fl + 2 * P.nsuper);
@@ -822,15 +822,16 @@ static void solve_m_async(hipfact_handle* h) {
            h->d_y.as<double>(), h->d_uvec.as<double>());
   }
   if (ltop < P.nlevels) {
-    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)2 * P.nsuper * sizeof(int), h->stream);
+    // two flag sets, one per sweep; each kernel clears the other one's (zero after upload_plan)
+    int* ffl = h->d_flags.as<int>();
+    int* bfl = ffl + 2 * P.nsuper;
     LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
            h->d_inv.as<int>(), h->d_ftarget.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>(),
-           h->d_flags.as<int>(), h->d_flags.as<int>() + P.nsuper, h->d_info.as<int>());
-    (void)hipMemsetAsync(h->d_flags.p, 0, (size_t)2 * P.nsuper * sizeof(int), h->stream);
+           ffl, ffl + P.nsuper, h->d_info.as<int>(), bfl, 2 * P.nsuper);
     LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
-           h->d_wpart.as<double>(), h->d_flags.as<int>(), h->d_flags.as<int>() + P.nsuper, h->d_info.as<int>());
+           h->d_wpart.as<double>(), bfl, bfl + P.nsuper, h->d_info.as<int>(), ffl, 2 * P.nsuper);
   }
   for (int l = ltop - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];

@@ -2159,8 +2159,10 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
                                                 const int* __restrict__ inv, const int* __restrict__ ftarget,
                                                 double* __restrict__ y, double* __restrict__ uvec,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
-                                                int* __restrict__ info) {
+                                                int* __restrict__ info, int* __restrict__ stale, int nstale) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // the flags of the opposite sweep are idle while this kernel runs: clear them for its next launch
+  for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   const TopItem& T = titems[blockIdx.x];
   if (T.kind != 0) {
 #pragma unroll
@@ -2192,8 +2194,9 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
                                                 const double* __restrict__ L, const int* __restrict__ rows,
                                                 double* __restrict__ y, double* __restrict__ wpart,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
-                                                int* __restrict__ info) {
+                                                int* __restrict__ info, int* __restrict__ stale, int nstale) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   // parents before children: workgroups are dispatched in index order, so a front never waits
   // for one that has not been dispatched yet (no co-residency assumption for correctness)
   const TopItem& T = titems[gridDim.x - 1 - blockIdx.x];
