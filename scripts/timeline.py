@@ -57,6 +57,14 @@ def build():
                   "      __syncthreads();\n      TRP(0);\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n        TRP(1);\n      } else {\n        pivot_gather_stage2(pc, invb, wp, lane, wave, v);", 1)
     s = s.replace("    __syncthreads();\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", "    __syncthreads();\n    TRP(2 + 2 * kb);\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", 1)
     s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n  }", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n    TRP(3 + 2 * kb);\n  }", 1)
+    # finer: inside a step, wave 0 (next diagonal tile, diagonal block) and wave 1 (trailing tiles, inverse row)
+    s = s.replace("#define TRP(slot)", "__device__ long long g_fine[4096 * 40];\n"
+                  "#define TRF(w, slot) if (threadIdx.x == 64 * (w)) g_fine[blockIdx.x * 40 + (slot)] = wall_clock64()\n#define TRP(slot)", 1)
+    s = s.replace("        if (!(phases & 64)) dev_trailing_tile(c, k0, kb + 1, kb + 1);\n        if (!(phases & 32)) dev_diag_block(c, scratch, k0 + 16, info);",
+                  "        if (!(phases & 64)) dev_trailing_tile(c, k0, kb + 1, kb + 1);\n        TRF(0, 4 * kb);\n        const long long cyc0 = __builtin_readcyclecounter();\n        if (!(phases & 32)) dev_diag_block(c, scratch, k0 + 16, info);\n        if (threadIdx.x == 0 && kb == 0) g_fine[blockIdx.x * 40 + 39] = __builtin_readcyclecounter() - cyc0;\n        TRF(0, 4 * kb + 1);", 1)
+    s = s.replace("    if (ROWINV && wave == 1 + (kb + 3) % 7) {", "    TRF(1, 4 * kb + 2);\n    if (ROWINV && wave == 1 + (kb + 3) % 7) {", 1)
+    s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    TRF(1, 4 * kb + 3);\n    __syncthreads();", 1)
+    assert s.count("TRF(") >= 5
     assert s.count("TRP(") >= 5
     assert s.count("TRW(") >= 8
     open(p, "w").write(s)
@@ -64,6 +72,8 @@ def build():
     t = open(h).read()
     t += ('\nextern "C" int hipfact_debug_trace(long long* out) {\n'
           "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * 4096 * 8);\n}\n"
+          'extern "C" int hipfact_debug_trace_fine(long long* out) {\n'
+          "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_fine), sizeof(long long) * 4096 * 40);\n}\n"
           'extern "C" int hipfact_debug_trace_pivot(long long* out) {\n'
           "  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_piv), sizeof(long long) * 4096 * 24);\n}\n")
     open(h, "w").write(t)
@@ -98,6 +108,10 @@ def run():
     lib.hipfact_debug_trace_pivot.argtypes = [C.c_void_p]
     assert lib.hipfact_debug_trace_pivot(piv.ctypes.data_as(C.c_void_p)) == 0
     piv = piv.reshape(4096, 24)
+    fine = np.zeros(4096 * 40, dtype=np.int64)
+    lib.hipfact_debug_trace_fine.argtypes = [C.c_void_p]
+    assert lib.hipfact_debug_trace_fine(fine.ctypes.data_as(C.c_void_p)) == 0
+    fine = fine.reshape(4096, 40)
     names = ["pivot", "panel", "schur"]
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
@@ -110,6 +124,10 @@ def run():
             st = [(x - base) / 100.0 for x in piv[i] if x > 0]
             print("        pivot detail (gathered, first diagonal block, then per step: block column done, step done): "
                   + " ".join(f"{x:.2f}" for x in st))
+            print("        shader-clock ticks of the diagonal block of step 0:", fine[i][39])
+            fs = [(x - base) / 100.0 for x in fine[i][:39] if x > 0]
+            print("        per step: wave 0 next diagonal tile updated, diagonal block done; wave 1 trailing tiles done, inverse row done: "
+                  + " ".join(f"{x:.2f}" for x in fs))
 
 
 if __name__ == "__main__":

@@ -130,7 +130,7 @@ struct hipfact_handle {
   std::vector<GraphEntry> graphs;
   int debug_phases = 15;
   int split_max_fronts = 1 << 30;
-  int factor_top_max = 100;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
@@ -540,20 +540,26 @@ static int upload_plan(hipfact_handle* h) {
           t.target = (sn[s].r - sn[s].w + t.crows - 1) / t.crows;
           return t;
         };
-        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-          const int s = P.level_sn[q];
+        // Workgroups are dispatched in index order and a waiting one keeps its CU.  Pivot items:
+        // widest front first (the level lasts as long as its slowest pivot).  Panel and Schur
+        // items: narrowest front first - their pivots finish first, so on a level with more
+        // workgroups than CUs the early slots go to work that is about to become ready.
+        std::vector<int> wide_first(P.level_sn.begin() + P.level_ptr[l], P.level_sn.begin() + P.level_ptr[l + 1]);
+        std::stable_sort(wide_first.begin(), wide_first.end(), [&](int a, int b) {
+          return sn[a].w != sn[b].w ? sn[a].w > sn[b].w : sn[a].r > sn[b].r;
+        });
+        std::vector<int> narrow_first(wide_first.rbegin(), wide_first.rend());
+        for (int s : wide_first) {
           tf.push_back(base(s, 0, 0));
           const size_t wp = (size_t)((sn[s].w + 15) & ~15);
           lds = std::max(lds, (wp + 2 * (size_t)(2 * 64 * 32 + 64 * MAXCH)) * sizeof(double));
         }
-        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-          const int s = P.level_sn[q];
+        for (int s : narrow_first) {
           const int u = sn[s].r - sn[s].w;
           const int crows = fine ? 64 : 128;
           for (int b = 0; b < (u + crows - 1) / crows; ++b) tf.push_back(base(s, 1, b));
         }
-        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
-          const int s = P.level_sn[q];
+        for (int s : narrow_first) {
           const int u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
           std::vector<int> tiles;
           for (int I = 0; I < nt; ++I)

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 //       below PULL instead: each gathers the children's entries of exactly what it is about to
 //       use (inverse relative indices, child order => same bits as the scatter form).
 //   B   blocked LDL^T (nb = 16) of the w x w pivot block in LDS:
-//         S1  16x16 diagonal block: LDL^T and its inverse in registers of one wave, one pass
-//             through the LDS crossbar per pivot (ds_bpermute / ds_swizzle), no LDS memory
+//         S1  16x16 diagonal block: LDL^T and its inverse in registers of one wave; every lane
+//             of a 16-lane row holds a whole matrix row, so a pivot step is one reciprocal and a
+//             run of v_fmac_f64 with a DPP row broadcast on their first source (no LDS at all)
 //         S2  block column  L_Ik = A_Ik inv(L_kk)^T D^-1          (MFMA)
 //         S3  trailing update A_IJ -= L_Ik D L_Jk^T                (MFMA), look-ahead: wave 0
 //             factors the next diagonal block meanwhile, and the other waves also form the
@@ -161,15 +162,6 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 // ---------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-
-// broadcast of a double from a compile-time-known lane: two v_readlane_b32
-// (scalar path, a few cycles) instead of a ds_bpermute round trip through LDS
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), src_lane);
-  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src_lane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 // 1/d to ~1 ulp without the IEEE division sequence.  v_rcp_f64 is good to 2^-24.4 on gfx950
 // (scripts/probe/rcp_f64_precision.hip), so ONE cubic step x0 (1 + e + e^2), e = 1 - d x0, leaves
@@ -294,45 +286,52 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
   }
 }
 
-// 16 x 16 diagonal block kb: LDL^T and the inverse of its unit lower factor in
-// the registers of ONE wave.  lane (i = li, q = lk) owns A[i][4q..4q+3] and
-// X[i][4q..4q+3]; the cross-lane exchange goes through a 32-double LDS scratch
-// (LDS operations of one wave execute in order: a write followed by reads needs
-// no barrier).  Leaves inv(L_kk) in the block and the pivots in dd.
-// lane exchange without LDS memory: the crossbar moves registers in ONE pass, where a write
-// followed by a read costs two dependent ones
-__device__ __forceinline__ double bperm_f64(double v, int src_lane) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(bits & 0xffffffffLL));
-  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(bits >> 32));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// value of lane K of the own 16-lane row (swizzle bit mode: lane' = (lane & 0x10) | K in groups of 32)
+// ---- 16 x 16 diagonal block kb: LDL^T and the inverse of its unit lower factor in the registers
+// of ONE wave.  Leaves inv(L_kk) in the block and the pivots in dd.
+// Lane exchange inside the 16-lane rows through the data-parallel path of the vector ALU.
+// gfx90a+ allows exactly one DPP control for 64-bit operands, row_newbcast:K (every lane reads
+// lane K of its row), and it can sit on the first source of v_fmac_f64: broadcast and FMA are ONE
+// instruction of ~6.5 ns, where two ds_swizzle + FMA cost 12 ns to issue and 28 ns on a dependent
+// chain (scripts/probe/lane_exchange_latency.hip).  The compiler does not form the fused
+// instruction by itself, hence the assembly; the s_nop covers the two wait states the hardware
+// requires between a vector write of a register and its use as a DPP source (the hazard
+// recogniser does not look into inline assembly).
 template <int K>
-__device__ __forceinline__ double rowbcast_f64(double v) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_ds_swizzle((int)(bits & 0xffffffffLL), 0x10 | (K << 5));
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(bits >> 32), 0x10 | (K << 5));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+__device__ __forceinline__ double rowb_f64(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
+// acc += (lane K of the row: src) * mul
+template <int K>
+__device__ __forceinline__ void fmac_rowb_f64(double& acc, double src, double mul) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(src), "v"(mul), "n"(K));
 }
 
+// Elimination step K of the diagonal block.  Lane (i = li, q = lk) holds the WHOLE row i of the
+// (symmetric) block in a[0..15], replicated over q, and X[i][4 cc + q] in x[cc]: the multiplier
+// l_ik = A[i][k] / d_k is then a lane-local product and row k arrives by row broadcasts only -
+// nothing crosses the 16-lane rows, nothing goes through LDS.  X[k][j] = 0 for j > k, so the
+// slices cc > k / 4 of x are not touched yet.  nl is -l_ik of THIS step, computed at the end
+// of the previous one; the next pivot column is updated first.
 template <int K>
-__device__ __forceinline__ void diag_step(double (&a)[4], double (&x)[4], int li, int lk) {
-  constexpr int qk = K >> 2, kr = K & 3;
-  const double ck_i = bperm_f64(a[kr], (qk << 4) | li);  // A[i][k] from the lane (i, qk)
-  const double d = readlane_f64(a[kr], (qk << 4) | K);   // A[k][k] via the scalar path
-  double ckj[4], xk[4];
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) ckj[cc] = rowbcast_f64<K>(a[cc]);  // A[k][j] = A[j][k], j = 4 lk + cc
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) xk[cc] = rowbcast_f64<K>(x[cc]);   // X[k][j]
-  const double rm = (li > K) ? fast_rcp(d) : 0.0;  // rows i <= k are finished
-  const double l_ik = ck_i * rm;
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    a[cc] = fma(-l_ik, ckj[cc], a[cc]);  // columns j <= k are dead: whatever lands there is never read
-    x[cc] = fma(-l_ik, xk[cc], x[cc]);
+__device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], double& dsel, int li, double nl) {
+  double nl_next = 0.0;
+  if (K < 15) fmac_rowb_f64<K>(a[K + 1], a[K + 1], nl);
+  dsel = (li == K + 1) ? a[K + 1] : dsel;  // pivot k + 1 is final now
+  if (K < 14) {
+    const double d = rowb_f64<K + 1>(a[K + 1]);
+    const double am = (li > K + 1) ? -a[K + 1] : 0.0;  // rows i <= k + 1 are finished
+    nl_next = am * fast_rcp(d);
   }
+#pragma unroll
+  for (int j = K + 2; j < 16; ++j) fmac_rowb_f64<K>(a[j], a[j], nl);  // columns j <= k are dead
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc)
+    if (4 * cc <= K) fmac_rowb_f64<K>(x[cc], x[cc], nl);
+  return nl_next;
 }
 
 __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info) {
@@ -340,42 +339,41 @@ __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratc
   const int li = lane & 15, lk = lane >> 4;
   const int lda = c.lda;
   double* A = c.A;
-  double a[4], x[4];
+  double a[16], x[4];
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    // the block is kept as a full symmetric matrix in registers: row k doubles as column k
-    const int j = 4 * lk + cc;
-    a[cc] = (li >= j) ? A[(k0 + li) + (k0 + j) * lda] : A[(k0 + j) + (k0 + li) * lda];
-    x[cc] = (li == j) ? 1.0 : 0.0;
+  for (int j = 0; j < 16; ++j)  // full symmetric row from the stored lower triangle
+    a[j] = (li >= j) ? A[(k0 + li) + (k0 + j) * lda] : A[(k0 + j) + (k0 + li) * lda];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) x[cc] = (li == 4 * cc + lk) ? 1.0 : 0.0;
+  // The dependent chain of the whole front runs through these steps (pivot -> reciprocal ->
+  // multiplier -> update of the next pivot column): no selects on the chain; singular /
+  // negative pivots are counted afterwards (a zero pivot floods the block with non-finite
+  // values; the factorisation is reported singular either way).
+  double dsel = a[0];  // pivot 0 (lane li = 0 keeps it)
+  double nl;
+  {
+    const double d = rowb_f64<0>(a[0]);
+    const double am = (li > 0) ? -a[0] : 0.0;
+    nl = am * fast_rcp(d);
   }
-  // The dependent chain of the whole front runs through these 16 steps (pivot -> multiplier ->
-  // update of the next pivot): one crossbar pass per step, no selects on the chain; singular /
-  // negative pivots are counted afterwards from the diagonal, which is final once its row has
-  // been eliminated (a zero pivot floods the block with non-finite values; the factorisation
-  // is reported singular either way).
-  diag_step<0>(a, x, li, lk);
-  diag_step<1>(a, x, li, lk);
-  diag_step<2>(a, x, li, lk);
-  diag_step<3>(a, x, li, lk);
-  diag_step<4>(a, x, li, lk);
-  diag_step<5>(a, x, li, lk);
-  diag_step<6>(a, x, li, lk);
-  diag_step<7>(a, x, li, lk);
-  diag_step<8>(a, x, li, lk);
-  diag_step<9>(a, x, li, lk);
-  diag_step<10>(a, x, li, lk);
-  diag_step<11>(a, x, li, lk);
-  diag_step<12>(a, x, li, lk);
-  diag_step<13>(a, x, li, lk);
-  diag_step<14>(a, x, li, lk);
-  diag_step<15>(a, x, li, lk);
+  nl = diag_step<0>(a, x, dsel, li, nl);
+  nl = diag_step<1>(a, x, dsel, li, nl);
+  nl = diag_step<2>(a, x, dsel, li, nl);
+  nl = diag_step<3>(a, x, dsel, li, nl);
+  nl = diag_step<4>(a, x, dsel, li, nl);
+  nl = diag_step<5>(a, x, dsel, li, nl);
+  nl = diag_step<6>(a, x, dsel, li, nl);
+  nl = diag_step<7>(a, x, dsel, li, nl);
+  nl = diag_step<8>(a, x, dsel, li, nl);
+  nl = diag_step<9>(a, x, dsel, li, nl);
+  nl = diag_step<10>(a, x, dsel, li, nl);
+  nl = diag_step<11>(a, x, dsel, li, nl);
+  nl = diag_step<12>(a, x, dsel, li, nl);
+  nl = diag_step<13>(a, x, dsel, li, nl);
+  nl = diag_step<14>(a, x, dsel, li, nl);
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * lk + cc) * lda] = x[cc];
-  // pivot of column li: the diagonal entry, held by the lane (li, lk = li / 4)
-  double dsel = a[0];
-#pragma unroll
-  for (int cc = 1; cc < 4; ++cc) dsel = ((li & 3) == cc) ? a[cc] : dsel;
-  const bool owner = (lk == (li >> 2));
+  for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * cc + lk) * lda] = x[cc];
+  const bool owner = (lk == 0);
   const bool bad = owner && ((dsel == 0.0) || !(fabs(dsel) <= 1.7e308));  // exactly singular or non-finite
   const bool neg = owner && !bad && (dsel < 0.0);
   if (owner) c.dd[k0 + li] = bad ? 1.0 : dsel;
@@ -683,9 +681,13 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       }
       if (!(phases & 64)) {
         // remaining tiles over the other waves (over all waves when there is only one)
-        const int first = (nw > 1) ? 1 + (wave - 1) : 1;
-        const int step = (nw > 1) ? nw - 1 : 1;
-        if (nw == 1 || wave > 0)
+        // wave 0 carries the sequential chain; with eight waves, wave 4 shares its SIMD (and the
+        // fp64 pipe that the MFMAs of a trailing tile keep busy), so it takes no tiles either
+        const bool quiet4 = (nw == 8);
+        const int widx = quiet4 ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;
+        const int first = (nw > 1) ? 1 + widx : 1;
+        const int step = (nw > 1) ? (quiet4 ? 6 : nw - 1) : 1;
+        if (nw == 1 || (wave > 0 && !(quiet4 && wave == 4)))
           for (int t = first; t < ntiles; t += step) {
             int J = 0, rem = t;
             while (rem >= T - J) {
@@ -704,8 +706,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         if (row < w && col <= row) c.P[row + (long long)col * r] = (row == col) ? dd[col] : A[row + col * lda];
       }
     }
-    if (ROWINV && wave >= 1 && wave - 1 < kb && !(phases & 128)) {
-      const int j = wave - 1;
+    // tile j of the row on wave j + 1, except that wave 4 stays off the SIMD of the chain: it takes
+    // the tile that only exists in the last step (j = 6, kb = 7), when no diagonal block is in flight
+    const int xj = (wave < 4) ? wave - 1 : (wave == 4 ? 6 : wave - 2);
+    if (ROWINV && wave >= 1 && xj < kb && !(phases & 128)) {
+      const int j = xj;
       d4_t t = {0.0, 0.0, 0.0, 0.0};
       for (int i = j; i < kb; ++i)
 #pragma unroll
