@@ -376,7 +376,10 @@ __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratc
   const bool owner = (lk == 0);
   const bool bad = owner && ((dsel == 0.0) || !(fabs(dsel) <= 1.7e308));  // exactly singular or non-finite
   const bool neg = owner && !bad && (dsel < 0.0);
-  if (owner) c.dd[k0 + li] = bad ? 1.0 : dsel;
+  if (owner) {
+    c.dd[k0 + li] = bad ? 1.0 : dsel;
+    scratch[li] = fast_rcp(bad ? 1.0 : dsel);  // 1 / d for the block column (S2) of this step
+  }
   const int nzero = __popcll(__ballot(bad)), nneg = __popcll(__ballot(neg));
   if (lane == 0 && (nzero | nneg)) {
     if (nzero) atomicAdd(&info[INFO_ZERO_PIVOT], nzero);
@@ -525,7 +528,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   double* A = c.A;
   double* dd = c.dd;
   double* Yp = c.Yp;
-  double* scratch = Yp + 16 * lda;  // 32 doubles for the diagonal-block micro-kernel
+  double* scratch = Yp + 16 * lda;  // 32 doubles: the reciprocal pivots of the current diagonal block
   const double* __restrict__ P = c.P;
   if (pc.n > 0) {
     // pull-mode extend-add (8 waves, wp <= 128).  Order of issue = order of the dependent round
@@ -662,7 +665,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
           const double bv = A[(k0 + li) + (k0 + 4 * s + lk) * lda];
           acc = MFMA_F64(av, bv, acc);
         }
-        const double dinv = 1.0 / dd[k0 + li];
+        const double dinv = scratch[li];  // left by the diagonal block
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = 16 * I + lk + 4 * q;
