@@ -151,6 +151,7 @@ struct hipfact_handle {
   DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_ftarget, d_wpart, d_pullx;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
+  DevBuf d_ysol;  // polled copy of the solution of M y = t (single-launch backward sweep)
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
   PinBuf h_norms;
   PinBuf h_stage, h_info;
@@ -622,7 +623,6 @@ static int upload_plan(hipfact_handle* h) {
           T.parent = sn[s].parent;
           const int nch = sn[s].child_end - sn[s].child_begin;
           const long long u = T.r - T.w;
-          long long sum_uc = 0, max_uc = 0;
           T.nchild = nch <= MAXCH ? nch : -1;
           for (int k = 0; k < nch && nch <= MAXCH; ++k) {
             const int ch = P.child_idx[sn[s].child_begin + k];
@@ -632,11 +632,9 @@ static int upload_plan(hipfact_handle* h) {
             T.c_id[k] = ch;
             T.c_invoff[k] = sn[ch].pad1;
             T.c_wait[k] = P.sn_level[ch] >= lvl ? ftarget[ch] : 0;
-            sum_uc += T.c_uc[k];
-            max_uc = std::max<long long>(max_uc, T.c_uc[k]);
           }
           size_t lf = h->levels[l].lds_fwd, lb = h->levels[l].lds_bwd;
-          if (h->top_prefetch && T.nchild >= 0 && sum_uc <= TOP_REL_CAP && max_uc <= SB && u * T.w <= TOP_L21_CAP) {
+          if (h->top_prefetch && T.nchild >= 0 && T.r <= 1024 && u * T.w <= TOP_L21_CAP) {  // one front row per thread
             T.prefetch |= 1;
             lf = ((size_t)T.r + 9 * (size_t)T.w + 1024 + TOP_REL_CAP / 2 + (size_t)(u * T.w) + 2) * sizeof(double);
           }
@@ -699,6 +697,11 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_U.ensure(std::max<size_t>((size_t)P.U_size * sizeof(double), 16)));
   HCHECK(h, h->d_uvec.ensure(std::max<size_t>((size_t)P.u_size * sizeof(double), 16)));
   HCHECK(h, h->d_y.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+  // exchanged element by element in the single-launch solve sweeps: every slot starts as the
+  // sentinel (all bits set) and is put back by the opposite sweep after use
+  HCHECK(h, h->d_ysol.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+  HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), h->stream));
+  HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), h->stream));
   const size_t nb = std::max<size_t>((size_t)P.N * sizeof(double), 16);
   HCHECK(h, h->d_rhs.ensure(nb));
   HCHECK(h, h->d_sol.ensure(nb));
@@ -834,10 +837,11 @@ static void solve_m_async(hipfact_handle* h) {
     LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
            h->d_inv.as<int>(), h->d_ftarget.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>(),
-           ffl, ffl + P.nsuper, h->d_info.as<int>(), bfl, 2 * P.nsuper);
+           ffl, ffl + P.nsuper, h->d_info.as<int>(), bfl, 2 * P.nsuper, h->d_ysol.as<double>());
     LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
-           h->d_wpart.as<double>(), bfl, bfl + P.nsuper, h->d_info.as<int>(), ffl, 2 * P.nsuper);
+           h->d_wpart.as<double>(), bfl, bfl + P.nsuper, h->d_info.as<int>(), ffl, 2 * P.nsuper,
+           h->d_ysol.as<double>(), h->d_uvec.as<double>());
   }
   for (int l = ltop - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];

@@ -1396,15 +1396,44 @@ __device__ __forceinline__ void dev_fwd_front(const SnDesc& S, const SnDesc* __r
 
 __device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info, int target = 1);
 
+// ---- data as its own flag (single-launch solve sweeps).  A dependent hop through a flag costs
+// three memory round trips in a row: the producer's release, the consumer's poll seeing the flag,
+// then the consumer's loads of the data.  The vectors exchanged between fronts are small, so the
+// ordinary fronts exchange them element by element instead: every element is stored with an
+// agent-scope atomic store and the consumer polls the element itself until it no longer holds
+// the sentinel (all bits set: a NaN that no arithmetic produces) - one round trip.  The slots are
+// put back to the sentinel by the opposite sweep (update vectors: backward item of the front;
+// solution copy ysol: forward item of the front), i.e. in a different launch.
+constexpr unsigned long long SOLVE_SENT = ~0ull;
+__device__ __forceinline__ double poll_f64(const double* __restrict__ p, int* __restrict__ info) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long bits;
+  int spins = 0;
+  while ((bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == SOLVE_SENT) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 20)) {
+      atomicAdd(&info[INFO_TIMEOUT], 1);
+      break;
+    }
+  }
+  return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ void post_f64(double* __restrict__ p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sent_f64(double* __restrict__ p) {
+  *reinterpret_cast<unsigned long long*>(p) = SOLVE_SENT;
+}
+
 // Forward step of one front inside the single-launch top-of-tree kernel.  Everything that does
 // not depend on the children is requested BEFORE the wait for their flags: own right-hand side,
 // the children's relative indices (LDS), this thread's fragments of inv(L11) (registers) and L21
 // (LDS).  After the wait only the children's update vectors are one memory round trip away.
 // Same arithmetic, in the same order, as dev_fwd_front.
 __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double* __restrict__ L,
-                                                  const int* __restrict__ rel, double* __restrict__ y,
-                                                  double* __restrict__ uvec, double* lds, int* __restrict__ flags,
-                                                  int* __restrict__ info) {
+                                                  const int* __restrict__ inv, double* __restrict__ y,
+                                                  double* __restrict__ uvec, double* lds, int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r, u = r - w;
   const double* __restrict__ P = L + T.Loff;
@@ -1412,19 +1441,12 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
   double* xs = f + r;         // w
   double* ps = xs + w;        // 8 x w partial sums of the triangular product
   double* part = ps + 8 * w;  // <= 1024 partial sums of the rectangular product
-  int* relc = reinterpret_cast<int*>(part + 1024);  // TOP_REL_CAP ints
   double* Lb = part + 1024 + TOP_REL_CAP / 2;       // u x w, column-major
-  for (int t = tid; t < r; t += SB) f[t] = (t < w) ? y[T.c0 + t] : 0.0;
-  {
-    int off = 0;
+  // front row tid (r <= SB): own right-hand side and, per child, which of its update rows lands here
+  double f0 = (tid < w) ? y[T.c0 + tid] : 0.0;
+  int iv[MAXCH];
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < T.nchild) {
-        const int* __restrict__ rc = rel + T.c_reloff[ch];
-        for (int a = tid; a < T.c_uc[ch]; a += SB) relc[off + a] = rc[a];
-        off += T.c_uc[ch];
-      }
-  }
+  for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < r) ? inv[T.c_invoff[ch] + tid] : -1;
   // row k of inv(L11), eighth p of the column range [0, k): at most 16 entries
   const int xk = tid & 127, xp = tid >> 7;
   const int xlo = (int)(((long long)xk * xp) >> 3), xhi = (int)(((long long)xk * (xp + 1)) >> 3);
@@ -1440,29 +1462,12 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
       for (int c = 0; c < 4; ++c)
         if (k0 + c < w) Lb[a + (k0 + c) * u] = v[c];
     }
-  // ---- dependency wait
-  bool waited = false;
+  // ---- the children's contributions, polled element by element, added in child order
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch)
-    if (ch < T.nchild && T.c_wait[ch]) {
-      top_wait(flags, T.c_id[ch], info, T.c_wait[ch]);
-      waited = true;
-    }
-  if (!waited) __syncthreads();
-  {
-    // all children's update vectors leave together (uc <= SB each); they are added child by child
-    double uvv[MAXCH];
-#pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) uvv[ch] = (ch < T.nchild && tid < T.c_uc[ch]) ? uvec[T.c_uoff[ch] + tid] : 0.0;
-    int off = 0;
-#pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < T.nchild) {
-        if (tid < T.c_uc[ch]) f[relc[off + tid]] += uvv[ch];
-        off += T.c_uc[ch];
-        __syncthreads();
-      }
-  }
+    if (iv[ch] >= 0) f0 += poll_f64(uvec + T.c_uoff[ch] + iv[ch], info);
+  if (tid < r) f[tid] = f0;
+  __syncthreads();
   if (xk < w) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const int n = xhi - xlo, n4 = n & ~3;
@@ -1506,7 +1511,7 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
             s3 += Lr[(k + 3) * u] * xs[k + 3];
           }
           for (; k < w; ++k) s0 += Lr[k * u] * xs[k];
-          us[a] = f[w + a] - ((s0 + s1) + (s2 + s3));
+          post_f64(us + a, f[w + a] - ((s0 + s1) + (s2 + s3)));
         }
       }
     } else {
@@ -1532,7 +1537,7 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
       for (int a = tid; a < u; a += SB) {
         double s = 0.0;
         for (int sl2 = 0; sl2 < nslice; ++sl2) s += part[sl2 * (nchunk << 6) + a];
-        us[a] = f[w + a] - s;
+        post_f64(us + a, f[w + a] - s);
       }
     }
   }
@@ -1553,7 +1558,8 @@ __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn,
 // fragments have been requested, so their latency overlaps the dependency wait.
 __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __restrict__ L,
                                               const int* __restrict__ rows, double* __restrict__ y, double* lds,
-                                              int* __restrict__ flags = nullptr, int* __restrict__ info = nullptr) {
+                                              int* __restrict__ flags = nullptr, int* __restrict__ info = nullptr,
+                                              double* __restrict__ ysol = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = S.w, r = S.r, u = r - w;
   const double* __restrict__ P = L + S.Loff;
@@ -1652,7 +1658,10 @@ __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __r
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int k = 4 * (wave + 16 * p) + c;
-        if (k < w) y[S.c0 + k] = v[k] + s[c];
+        if (k < w) {
+          y[S.c0 + k] = v[k] + s[c];
+          if (ysol) post_f64(ysol + S.c0 + k, v[k] + s[c]);
+        }
       }
     }
   }
@@ -1672,7 +1681,7 @@ __device__ __forceinline__ void dev_bwd_front(const SnDesc& S, const double* __r
 template <bool TOP>
 __device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, int c0, int w, int r, int parent,
                                               const double* __restrict__ L, const int* __restrict__ rows,
-                                              double* __restrict__ y, double* lds, int* __restrict__ flags,
+                                              double* __restrict__ y, double* lds, double* __restrict__ ysol,
                                               int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -1692,11 +1701,16 @@ __device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, 
   double* part = ypre + wp;       // nsplit x wp <= 256 partial sums
   int* rwb = reinterpret_cast<int*>(part + 256);
   double* Xb = part + 256 + ((u + 1) >> 1);  // TOP: w x w, zero on and above the diagonal
+  int myrow = -1;  // TOP: update row tid (u <= 256 < SB) is polled by this thread
   for (int a = tid; a < 4 * nac; a += SB) {
-    if (a < u)
-      rwb[a] = rw[a];
-    else
+    if (a < u) {
+      if (TOP)
+        myrow = rw[a];
+      else
+        rwb[a] = rw[a];
+    } else {
       g[a] = 0.0;
+    }
   }
   for (int t = tid; t < wp + 4; t += SB) {
     if (t < w)
@@ -1722,11 +1736,13 @@ __device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, 
     const int a = 4 * (c_lo + j) + lk;
     lv[j] = (active && c_lo + j < c_hi && k < w && a < u) ? P[w + a + (long long)k * r] : 0.0;
   }
-  if (TOP && parent >= 0)
-    top_wait(flags, parent, info);  // the parent is done only after all its ancestors
-  else
+  if (TOP) {
+    // the ancestors' solution entries, polled one by one (no flag, no fence: see poll_f64)
+    if (myrow >= 0) g[tid] = poll_f64(ysol + myrow, info);
+  } else {
     __syncthreads();
-  for (int a = tid; a < u; a += SB) g[a] = y[rwb[a]];
+    for (int a = tid; a < u; a += SB) g[a] = y[rwb[a]];
+  }
   __syncthreads();
   if (active) {
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -1776,6 +1792,7 @@ __device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, 
     double s = 0.0;
     for (int q = 0; q < nsplit; ++q) s += part[q * wp + t];
     y[c0 + t] = v[t] + s;
+    if (TOP) post_f64(ysol + c0 + t, v[t] + s);
   }
 }
 
@@ -2111,7 +2128,7 @@ __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const doubl
 __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double* __restrict__ L,
                                                   double* __restrict__ y, const double* __restrict__ wpart,
                                                   double* lds, int* __restrict__ flags, int* __restrict__ hflags,
-                                                  int* __restrict__ info) {
+                                                  int* __restrict__ info, double* __restrict__ ysol) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r;
   const double* __restrict__ P = L + T.Loff;
@@ -2156,7 +2173,10 @@ __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0 && k < w) y[T.c0 + k] = v[k] + s;
+    if (lane == 0 && k < w) {
+      y[T.c0 + k] = v[k] + s;
+      post_f64(ysol + T.c0 + k, v[k] + s);
+    }
   }
 }
 
@@ -2167,11 +2187,15 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
                                                 const int* __restrict__ inv, const int* __restrict__ ftarget,
                                                 double* __restrict__ y, double* __restrict__ uvec,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
-                                                int* __restrict__ info, int* __restrict__ stale, int nstale) {
+                                                int* __restrict__ info, int* __restrict__ stale, int nstale,
+                                                double* __restrict__ ysol) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // the flags of the opposite sweep are idle while this kernel runs: clear them for its next launch
   for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   const TopItem& T = titems[blockIdx.x];
+  // ... and so is the polled copy of the solution: the front's pivot entries go back to the sentinel
+  if (T.kind != 2)
+    for (int k = threadIdx.x; k < T.w; k += SB) sent_f64(ysol + T.c0 + k);
   if (T.kind != 0) {
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
@@ -2186,7 +2210,7 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
     return;
   }
   if (T.prefetch & 1) {
-    dev_fwd_front_top(T, L, rel, y, uvec, lds, flags, info);
+    dev_fwd_front_top(T, L, inv, y, uvec, lds, info);
   } else {
     const SnDesc S = sn[T.s];
     for (int ci = S.child_begin; ci < S.child_end; ++ci) {
@@ -2202,27 +2226,33 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
                                                 const double* __restrict__ L, const int* __restrict__ rows,
                                                 double* __restrict__ y, double* __restrict__ wpart,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
-                                                int* __restrict__ info, int* __restrict__ stale, int nstale) {
+                                                int* __restrict__ info, int* __restrict__ stale, int nstale,
+                                                double* __restrict__ ysol, double* __restrict__ uvec) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   // parents before children: workgroups are dispatched in index order, so a front never waits
   // for one that has not been dispatched yet (no co-residency assumption for correctness)
   const TopItem& T = titems[gridDim.x - 1 - blockIdx.x];
+  // the update vector of the front was consumed by its parent in the forward launch: back to the sentinel
+  if (T.kind == 0)
+    for (int a = threadIdx.x; a < T.r - T.w; a += SB) sent_f64(uvec + T.uoff + a);
+  else if (T.kind == 2)
+    for (int a = T.a0 + threadIdx.x; a < T.a1; a += SB) sent_f64(uvec + T.uoff + a);
   if (T.kind == 2) {
     dev_bwd_wide_slice(T, L, rows, y, wpart, lds, flags, info);  // awaits the parent after its prefetch
     top_publish_add(hflags, T.s);
     return;
   }
   if (T.kind == 1) {
-    dev_bwd_wide_head(T, L, y, wpart, lds, flags, hflags, info);  // awaits its slices after its prefetch
+    dev_bwd_wide_head(T, L, y, wpart, lds, flags, hflags, info, ysol);  // awaits its slices after its prefetch
     top_publish(flags, T.s);
     return;
   }
   if (T.prefetch & 2) {
-    dev_bwd_small<true>(T.Loff, T.rowoff, T.c0, T.w, T.r, T.parent, L, rows, y, lds, flags, info);
+    dev_bwd_small<true>(T.Loff, T.rowoff, T.c0, T.w, T.r, T.parent, L, rows, y, lds, ysol, info);
   } else {
     const SnDesc S = sn[T.s];
-    dev_bwd_front(S, L, rows, y, lds, flags, info);
+    dev_bwd_front(S, L, rows, y, lds, flags, info, ysol);
   }
   top_publish(flags, T.s);
 }

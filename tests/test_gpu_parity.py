@@ -442,6 +442,45 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
 
+def test_solve_sequence_with_changing_right_hand_sides(fact):
+    """The single-launch solve sweeps exchange vectors element by element through slots that the
+    opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
+    the PREVIOUS solve to the next one: a sequence of different right-hand sides (mixed front
+    kinds: prefetching, generic and wide fronts, levels below the launch) against the
+    level-by-level path (bit for bit, except that wide fronts sum their slices in another order),
+    with a refactorisation in between."""
+    from sleqp_amd.sparse import SleqpMat
+
+    cases = [("b", 20000, 10000, {}), ("u", 3000, 1500, {"wide_min_rows": 300}), ("b", 20000, 10000, {"top_max_fronts": 200})]
+    for kind, n, m, opts in cases:
+        J, vi, ci, _ = _problem(n, m, kind, 0.0, 5)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        rng = np.random.default_rng(8)
+        rhs = [rng.standard_normal(N) * 10.0 ** rng.integers(-3, 4) for _ in range(5)]
+        rhs.insert(2, np.zeros(N))
+        fact.set_option("refine_steps", 0)
+        outs = {}
+        for top_max in (0, opts.get("top_max_fronts", 1024)):
+            fact.set_option("top_max_fronts", top_max)
+            fact.set_option("wide_min_rows", opts.get("wide_min_rows", 1024))
+            fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            res = []
+            for i, b in enumerate(rhs):
+                if i == 3:
+                    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))  # numeric refactorisation in the middle
+                fact.solve(b)
+                res.append(fact.solution_raw(0, N))
+                assert fact.info("solve_timeouts") == 0
+                assert scaled_residual(K, res[-1], b) <= 1e-9
+            outs[top_max] = res
+        a, c = outs.values()
+        for x, y in zip(a, c):
+            assert np.array_equal(x, y) if "wide_min_rows" not in opts else rel_err(x, y) <= 1e-10
+    fact.set_option("top_max_fronts", 1024)
+    fact.set_option("wide_min_rows", 1024)
+
+
 def test_pull_with_more_children_than_one_descriptor_block(fact):
     """Fronts with more than four children (amalgamation unconstrained): the gathers walk a chain of
     descriptor blocks, in child order - identical bits to the scatter kernel."""
