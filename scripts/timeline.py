@@ -36,11 +36,9 @@ def build():
                       "  TRW(0);\n  if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 7] = T.role * 100000 + T.front;\n"
                       "  ChildWait cw;\n  cw.n = T.nwait;", 1)
     seg = seg.replace("    flag_publish_add(&bdone[T.front]);", "    TRW(2);\n    flag_publish_add(&bdone[T.front]);\n    TRW(3);", 1)
-    seg = seg.replace("    flag_wait_ge(&bdone[T.front], 1, info);", "    TRW(5);\n    flag_wait_ge(&bdone[T.front], 1, info);\n    TRW(1);", 1)
+    seg = seg.replace("    dev_panel_rows_product_posted(", "    TRW(1);\n    dev_panel_rows_product_posted(", 1)
     seg = seg.replace("    flag_publish_add(&cdone[T.front]);", "    TRW(2);\n    flag_publish_add(&cdone[T.front]);\n    TRW(3);", 1)
     seg = seg.replace("    flag_publish_add(&ddone[T.front]);", "    TRW(2);\n    flag_publish_add(&ddone[T.front]);\n    TRW(3);", 1)
-    seg = seg.replace("    dev_load_pivot_block(c, true);\n    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);",
-                      "    dev_load_pivot_block(c, true);\n    TRW(4);\n    if (R0 < c.r) dev_panel_rows_product<true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);", 1)
     s = s[:a] + seg + s[b:]
     s = s.replace("    cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited",
                   "    if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
@@ -66,7 +64,7 @@ def build():
     s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    TRF(1, 4 * kb + 3);\n    __syncthreads();", 1)
     assert s.count("TRF(") >= 5
     assert s.count("TRP(") >= 5
-    assert s.count("TRW(") >= 8
+    assert s.count("TRW(") >= 7
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "hipfact.hip")
     t = open(h).read()
@@ -116,7 +114,7 @@ def run():
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
     for i in range(max(0, n - 60), n):
-        extra = f"  inv(L11) staged {tt[i, 4]:8.2f}" if role[i] == 1 else ""
+        extra = ""
         print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {tt[i, 5]:8.2f}  waited {tt[i, 1]:8.2f}"
               f"  done {tt[i, 2]:8.2f}  published {tt[i, 3]:8.2f}{extra}")
         if role[i] == 0 and i >= n - 16:

@@ -59,7 +59,8 @@ struct TopFItem {
   int wait_cnt[MAXCH];  // Schur workgroups of each child in this launch (0: finished before the launch)
   int target;           // Schur: panel workgroups of the own front
   int crows;            // panel: rows per workgroup (128, or 64 with two waves per 16-row strip)
-  int pad[2];
+  int sidx, scount;     // Schur: index among / number of the Schur workgroups of the front
+  long long xoff;       // the front's wp x wp slot in the arena of posted pivot blocks
 };
 
 // one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)

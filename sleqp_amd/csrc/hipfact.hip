@@ -151,6 +151,7 @@ struct hipfact_handle {
   DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_ftarget, d_wpart, d_pullx;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
+  DevBuf d_xarena;  // posted pivot blocks of the single-launch factorisation (polled by its panel workgroups)
   DevBuf d_ysol;  // polled copy of the solution of M y = t (single-launch backward sweep)
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
   PinBuf h_norms;
@@ -513,6 +514,18 @@ static int upload_plan(hipfact_handle* h) {
       };
       std::vector<TopFItem> tf;
       size_t lds = 0;
+      // slots of the posted pivot blocks (wp x wp each), all sentinel between factorisations
+      std::vector<long long> xoff(ns, 0);
+      long long xsize = 0;
+      for (int l = lvl; l < P.nlevels; ++l)
+        for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+          const int s = P.level_sn[q];
+          const long long wp = (sn[s].w + 15) & ~15;
+          xoff[s] = xsize;
+          xsize += wp * wp;
+        }
+      HCHECK(h, h->d_xarena.ensure(std::max<size_t>((size_t)xsize * sizeof(double), 16)));
+      HCHECK(h, hipMemsetAsync(h->d_xarena.p, 0xFF, std::max<size_t>((size_t)xsize * sizeof(double), 16), h->stream));
       for (int l = lvl; l < P.nlevels; ++l) {
         const LevelInfo& li = h->levels[l];
         lds = std::max({lds, li.lds_pivot, li.lds_panel});
@@ -538,6 +551,7 @@ static int upload_plan(hipfact_handle* h) {
             t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)(h->levels[P.sn_level[ch]].count <= h->factor_top_fine ? ntiles(ch) : (ntiles(ch) + 1) / 2) : 0;
           }
           t.crows = fine ? 64 : 128;
+          t.xoff = xoff[s];
           t.target = (sn[s].r - sn[s].w + t.crows - 1) / t.crows;
           return t;
         };
@@ -565,9 +579,12 @@ static int upload_plan(hipfact_handle* h) {
           std::vector<int> tiles;
           for (int I = 0; I < nt; ++I)
             for (int J = 0; J <= I; ++J) tiles.push_back((I << 16) | J);
-          for (size_t k = 0; k < tiles.size(); k += (fine ? 1 : 2)) {
+          const int stride = fine ? 1 : 2;
+          for (size_t k = 0; k < tiles.size(); k += stride) {
             TopFItem t = base(s, 2, tiles[k]);
             t.part2 = fine ? -1 : tiles[std::min(k + 1, tiles.size() - 1)];
+            t.sidx = (int)(k / stride);
+            t.scount = (int)((tiles.size() + stride - 1) / stride);
             tf.push_back(t);
           }
         }
@@ -789,7 +806,7 @@ static int factor_enqueue(hipfact_handle* h) {
     int* fl = reinterpret_cast<int*>(h->d_L.as<double>() + P.L_size);  // cleared with the L arena
     LAUNCH(PC_FACTOR_T, k_factor_top, dim3(h->ftop_count), dim3(512), h->ftop_lds, h->d_tfitems.as<TopFItem>(),
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
-           fl + P.nsuper, fl + 2 * P.nsuper);
+           fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>());
   }
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;

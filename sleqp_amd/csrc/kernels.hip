@@ -174,6 +174,37 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return fma(x, t, x);
 }
 
+// ---- data as its own flag (single-launch solve sweeps, pivot -> panel in the single-launch
+// factorisation).  A dependent hop through a flag costs
+// three memory round trips in a row: the producer's release, the consumer's poll seeing the flag,
+// then the consumer's loads of the data.  The vectors exchanged between fronts are small, so the
+// ordinary fronts exchange them element by element instead: every element is stored with an
+// agent-scope atomic store and the consumer polls the element itself until it no longer holds
+// the sentinel (all bits set: a NaN that no arithmetic produces) - one round trip.  The slots are
+// put back to the sentinel by the opposite sweep (update vectors: backward item of the front;
+// solution copy ysol: forward item of the front), i.e. in a different launch.
+constexpr unsigned long long SOLVE_SENT = ~0ull;
+__device__ __forceinline__ double poll_f64(const double* __restrict__ p, int* __restrict__ info) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long bits;
+  int spins = 0;
+  while ((bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == SOLVE_SENT) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 20)) {
+      atomicAdd(&info[INFO_TIMEOUT], 1);
+      break;
+    }
+  }
+  return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ void post_f64(double* __restrict__ p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sent_f64(double* __restrict__ p) {
+  *reinterpret_cast<unsigned long long*>(p) = SOLVE_SENT;
+}
+
 struct FrontCtx {
   int w, r, u, wp, nbk, lda;
   double* P;   // panel (global)
@@ -181,6 +212,7 @@ struct FrontCtx {
   double* dd;  // pivots (LDS)
   double* A;   // pivot block / inverse (LDS)
   double* Yp;  // block-column panel (LDS)
+  double* Xa;  // single-launch factorisation: where the finished tiles of inv(L11) are posted for the panel workgroups (else null)
 };
 
 template <class Desc>
@@ -197,6 +229,7 @@ __device__ __forceinline__ FrontCtx make_ctx(const Desc& S, double* L, double* U
   c.dd = lds;
   c.A = lds + c.wp;
   c.Yp = c.A + c.wp * c.lda;
+  c.Xa = nullptr;
   return c;
 }
 
@@ -651,7 +684,10 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * xrow + lk + 4 * q, col = 16 * xcol + li;
         A[row + col * lda] = -xpend[q];
-        if (row < w) c.P[row + (long long)col * r] = -xpend[q];  // final: straight to the panel as well
+        if (row < w) {
+          c.P[row + (long long)col * r] = -xpend[q];  // final: straight to the panel as well
+          if (c.Xa) post_f64(c.Xa + row + col * c.wp, -xpend[q]);  // ... and to the panel workgroups that poll for it
+        }
       }
       xrow = -1;
     }
@@ -706,7 +742,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = k0 + li, col = k0 + lk + 4 * q;
-        if (row < w && col <= row) c.P[row + (long long)col * r] = (row == col) ? dd[col] : A[row + col * lda];
+        if (row < w && col <= row) {
+          const double val = (row == col) ? dd[col] : A[row + col * lda];
+          c.P[row + (long long)col * r] = val;
+          if (c.Xa) post_f64(c.Xa + row + col * c.wp, val);
+        }
       }
     }
     // tile j of the row on wave j + 1, except that wave 4 stays off the SIMD of the chain: it takes
@@ -736,7 +776,10 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     for (int q = 0; q < 4; ++q) {
       const int row = 16 * xrow + lk + 4 * q, col = 16 * xcol + li;
       A[row + col * lda] = -xpend[q];
-      if (row < w) c.P[row + (long long)col * r] = -xpend[q];
+      if (row < w) {
+        c.P[row + (long long)col * r] = -xpend[q];
+        if (c.Xa) post_f64(c.Xa + row + col * c.wp, -xpend[q]);
+      }
     }
   }
   if (ROWINV) __syncthreads();
@@ -951,6 +994,57 @@ __device__ __forceinline__ void dev_panel_rows_product(const FrontCtx& c, int R0
           }
         }
       }
+  }
+}
+
+// Panel rows in the single-launch factorisation.  The pivot workgroup posts inv(L11) tile by tile
+// as the tiles become final (block row ct after step ct of its loop), and output block ct of
+// L21 = P21 inv(L11)^T D^-1 needs exactly block row ct: the panel workgroups poll the tiles
+// themselves (no flag, no fence, see poll_f64) and follow the pivot workgroup block row by block
+// row, so that only the last block row is left when the pivot block is finished.  Same products
+// in the same order as dev_panel_rows_product<true, true> (ct-major instead of tt-major nesting:
+// every accumulator still sees tt ascending).
+__device__ __forceinline__ void dev_panel_rows_product_posted(const FrontCtx& c, int R0, double (&pv)[8][4], int cstep,
+                                                              int c0, bool active, int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda, wp = c.wp;
+  double* A = c.A;
+  double* __restrict__ P = c.P;
+  const bool rok = active && (R0 + li) < r;
+  for (int ct = 0; ct < nbk; ++ct) {
+    // block row ct of X = inv(L11): tiles (ct, 0 .. ct), unit diagonal, and 1 / d of its 16 pivots
+    for (int e = tid; e < (ct + 1) * 256; e += blockDim.x) {
+      const int tt = e >> 8, i = e & 15, k = (e >> 4) & 15;
+      const int row = 16 * ct + i, col = 16 * tt + k;
+      double v = (row == col) ? 1.0 : 0.0;
+      if (row < w && col < row) v = poll_f64(c.Xa + row + col * wp, info);
+      A[row + col * lda] = v;
+    }
+    if (tid < 16) {
+      const int col = 16 * ct + tid;
+      c.dd[col] = (col < w) ? 1.0 / poll_f64(c.Xa + col + col * wp, info) : 1.0;
+    }
+    __syncthreads();
+    if (active && (ct % cstep) == c0) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt)
+        if (tt <= ct) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double xv = A[(16 * ct + li) + (16 * tt + 4 * s + lk) * lda];
+            acc = MFMA_F64(xv, pv[tt][s], acc);
+          }
+        }
+      if (rok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 16 * ct + lk + 4 * q;
+          if (col < w) P[(R0 + li) + (long long)col * r] = acc[q] * c.dd[col];
+        }
+      }
+    }
   }
 }
 
@@ -1396,35 +1490,6 @@ __device__ __forceinline__ void dev_fwd_front(const SnDesc& S, const SnDesc* __r
 
 __device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info, int target = 1);
 
-// ---- data as its own flag (single-launch solve sweeps).  A dependent hop through a flag costs
-// three memory round trips in a row: the producer's release, the consumer's poll seeing the flag,
-// then the consumer's loads of the data.  The vectors exchanged between fronts are small, so the
-// ordinary fronts exchange them element by element instead: every element is stored with an
-// agent-scope atomic store and the consumer polls the element itself until it no longer holds
-// the sentinel (all bits set: a NaN that no arithmetic produces) - one round trip.  The slots are
-// put back to the sentinel by the opposite sweep (update vectors: backward item of the front;
-// solution copy ysol: forward item of the front), i.e. in a different launch.
-constexpr unsigned long long SOLVE_SENT = ~0ull;
-__device__ __forceinline__ double poll_f64(const double* __restrict__ p, int* __restrict__ info) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  unsigned long long bits;
-  int spins = 0;
-  while ((bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == SOLVE_SENT) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 20)) {
-      atomicAdd(&info[INFO_TIMEOUT], 1);
-      break;
-    }
-  }
-  return __longlong_as_double((long long)bits);
-}
-__device__ __forceinline__ void post_f64(double* __restrict__ p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sent_f64(double* __restrict__ p) {
-  *reinterpret_cast<unsigned long long*>(p) = SOLVE_SENT;
-}
 
 // Forward step of one front inside the single-launch top-of-tree kernel.  Everything that does
 // not depend on the children is requested BEFORE the wait for their flags: own right-hand side,
@@ -1900,11 +1965,15 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
                                                    double* __restrict__ U, int* __restrict__ info,
                                                    const int* __restrict__ inv, const int* __restrict__ rel,
                                                    int* __restrict__ bdone, int* __restrict__ cdone,
-                                                   int* __restrict__ ddone) {
+                                                   int* __restrict__ ddone, double* __restrict__ xarena) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TopFItem& T = items[blockIdx.x];
   const FrontItem& S = T.it;
-  const FrontCtx c = make_ctx(S, L, U, lds);
+  FrontCtx c = make_ctx(S, L, U, lds);
+  // Levels with a handful of fronts (the latency-bound top of the tree) post the pivot block tile
+  // by tile for their panel workgroups; on wider levels hundreds of polling workgroups would
+  // flood the memory system for no gain (those levels are bound by occupancy), so they keep the flag.
+  c.Xa = (T.crows == 64) ? xarena + T.xoff : nullptr;
   const PullCtx pc = make_pull(S.pd, U, inv, rel, 1);
   ChildWait cw;
   cw.n = T.nwait;
@@ -1937,9 +2006,13 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     dev_panel_rows_load(c, R0, pc, pv, cis);
     __syncthreads();
     dev_panel_rows_gather(c, pc, invl, pv, cis);
-    flag_wait_ge(&bdone[T.front], 1, info);
-    dev_load_pivot_block(c, true, true);
-    if (R0 < c.r) dev_panel_rows_product<true, true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);
+    if (c.Xa) {
+      dev_panel_rows_product_posted(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0, R0 < c.r, info);
+    } else {
+      flag_wait_ge(&bdone[T.front], 1, info);
+      dev_load_pivot_block(c, true, true);
+      if (R0 < c.r) dev_panel_rows_product<true, true>(c, R0, pv, cstep, cstep == 2 ? (wv & 1) : 0);
+    }
     flag_publish_add(&cdone[T.front]);
   } else {
     // two 256-thread teams, one tile each (the same tile twice when the front has an odd number):
@@ -1950,6 +2023,10 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
     dev_schur_tile<false>(c, SI, SI + 64 * KC, ij < 0 ? -1 : (ij >> 16), ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255,
                           &cdone[T.front], T.target, info);
+    // every panel workgroup of the front has finished polling: its slot of posted tiles goes back
+    // to the sentinel for the next factorisation (a share per Schur workgroup)
+    if (c.Xa)
+      for (int e = T.sidx * 512 + threadIdx.x; e < c.wp * c.wp; e += T.scount * 512) sent_f64(c.Xa + e);
     flag_publish_add(&ddone[T.front]);
   }
 }
