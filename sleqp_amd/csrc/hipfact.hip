@@ -512,6 +512,10 @@ static int upload_plan(hipfact_handle* h) {
         const long long u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
         return nt * (nt + 1) / 2;
       };
+      auto ntiles32 = [&](int s) {
+        const long long u = sn[s].r - sn[s].w, nt = (u + 31) / 32;
+        return nt * (nt + 1) / 2;
+      };
       std::vector<TopFItem> tf;
       size_t lds = 0;
       // slots of the posted pivot blocks (wp x wp each), all sentinel between factorisations
@@ -548,7 +552,7 @@ static int upload_plan(hipfact_handle* h) {
           for (int k = 0; k < t.nwait; ++k) {
             const int ch = P.child_idx[sn[s].child_begin + k];
             t.wait_id[k] = ch;
-            t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)(h->levels[P.sn_level[ch]].count <= h->factor_top_fine ? ntiles(ch) : (ntiles(ch) + 1) / 2) : 0;
+            t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)(h->levels[P.sn_level[ch]].count <= h->factor_top_fine ? ntiles32(ch) : (ntiles(ch) + 1) / 2) : 0;
           }
           t.crows = fine ? 64 : 128;
           t.xoff = xoff[s];
@@ -575,7 +579,7 @@ static int upload_plan(hipfact_handle* h) {
           for (int b = 0; b < (u + crows - 1) / crows; ++b) tf.push_back(base(s, 1, b));
         }
         for (int s : narrow_first) {
-          const int u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
+          const int u = sn[s].r - sn[s].w, nt = fine ? (u + 31) / 32 : (u + 63) / 64;  // fine: 32 x 32 tiles
           std::vector<int> tiles;
           for (int I = 0; I < nt; ++I)
             for (int J = 0; J <= I; ++J) tiles.push_back((I << 16) | J);

@@ -1264,6 +1264,90 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     }
 }
 
+// ---- phase D on the narrow top levels of the single-launch factorisation: one 32 x 32 tile (I, J)
+// per workgroup.  There a 64 x 64 tile is bound by the matrix pipes of ONE CU (336 MFMAs on four
+// SIMDs) and by three staging round trips; with plenty of idle CUs the tile is cut in four, both
+// operand strips (32 rows x w each) are requested in ONE batch right after the wait, and each of
+// the waves 0..3 then owns one 16 x 16 block (w / 4 MFMAs).  Same products, same k order, same
+// child order as dev_schur_tile: identical bits.  All threads of the workgroup stage.
+// LDS (strips): 2 x wp x 32 doubles at c.A.
+__device__ __forceinline__ void dev_schur_tile32(const FrontCtx& c, int I, int J, const PullCtx& pc,
+                                                 int* __restrict__ wait_addr, int wait_target,
+                                                 int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, u = c.u;
+  const double* __restrict__ P21 = c.P + w;
+  double* SI = c.A;             // [k][32 rows of I]
+  double* SJ = c.A + 32 * c.wp;  // [k][32 rows of J] * d_k
+  const int wi = wave & 1, wj = (wave >> 1) & 1;
+  const bool mm = wave < 4 && !(I == J && wi < wj);  // this wave owns a block on or below the diagonal
+  // children's entries of the block (they finished long ago): maps, then gathers, before the wait
+  double uv[4] = {0.0, 0.0, 0.0, 0.0};
+  const int gi = 32 * I + 16 * wi + li;
+  if (mm) {
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < pc.n) {
+        const int ci = (gi < u) ? pc.inv[ch][w + gi] : -1;
+        int cj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gj = 32 * J + 16 * wj + lk + 4 * q;
+          cj[q] = (gj < u) ? pc.inv[ch][w + gj] : -1;
+        }
+        double g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = ci >= 0 && cj[q] >= 0 && ci >= cj[q];
+          const double gv = pc.Uc[ch][ok ? ci + (long long)cj[q] * pc.uc[ch] : 0];
+          g[q] = ok ? gv : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) uv[q] += g[q];
+      }
+  }
+  flag_wait_ge(wait_addr, wait_target, info);
+  // both strips in one batch: element e -> (k = e / 64, strip = (e / 32) & 1, row = e % 32)
+  {
+    double v[16], d[16];  // 64 wp <= 8192 elements
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = tid + 512 * t;
+      const int k = e >> 6, row = e & 31;
+      const bool js = (e >> 5) & 1;
+      const int g = js ? 32 * J + row : 32 * I + row;
+      v[t] = (k < w && g < u) ? P21[g + (long long)k * r] : 0.0;
+      d[t] = (k < w && js) ? c.P[k + (long long)k * r] : 1.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = tid + 512 * t;
+      const int k = e >> 6, row = e & 31;
+      if (k < c.wp) {
+        if ((e >> 5) & 1)
+          SJ[k * 32 + row] = v[t] * d[t];
+        else
+          SI[k * 32 + row] = v[t];
+      }
+    }
+  }
+  __syncthreads();
+  if (!mm) return;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < w; k0 += 4) {
+    const int kk = (k0 + lk) * 32;  // rows k >= w of the strips are zero (k < wp)
+    acc = MFMA_F64(SJ[kk + 16 * wj + li], SI[kk + 16 * wi + li], acc);
+  }
+  if (gi < u) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gj = 32 * J + 16 * wj + lk + 4 * q;
+      if (gj < u && gi >= gj) c.Us[gi + (long long)gj * u] = uv[q] - acc[q];
+    }
+  }
+}
+
 // fused: one workgroup per front, phases B, C, D (assembly has its own kernel)
 __global__ __launch_bounds__(FB) void k_factor_level(const SnDesc* __restrict__ sn,
                                                      const int* __restrict__ level_sn, double* __restrict__ L,
@@ -2018,11 +2102,15 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     // two 256-thread teams, one tile each (the same tile twice when the front has an odd number):
     // children's entries first, then the panel workgroups of the own front are awaited
     cw.wait();
-    const int team = threadIdx.x >> 8;
-    const int ij = team ? T.part2 : S.part;  // part2 < 0: the second team has no tile
-    double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
-    dev_schur_tile<false>(c, SI, SI + 64 * KC, ij < 0 ? -1 : (ij >> 16), ij & 0xffff, S.nchild == 0, pc, threadIdx.x & 255,
-                          &cdone[T.front], T.target, info);
+    if (T.crows == 64) {
+      dev_schur_tile32(c, S.part >> 16, S.part & 0xffff, pc, &cdone[T.front], T.target, info);
+    } else {
+      const int team = threadIdx.x >> 8;
+      const int ij = team ? T.part2 : S.part;  // part2 < 0: the second team has no tile
+      double* SI = c.A + (size_t)team * (2 * 64 * KC + 64 * MAXCH);
+      dev_schur_tile<false>(c, SI, SI + 64 * KC, ij < 0 ? -1 : (ij >> 16), ij & 0xffff, S.nchild == 0, pc,
+                            threadIdx.x & 255, &cdone[T.front], T.target, info);
+    }
     // every panel workgroup of the front has finished polling: its slot of posted tiles goes back
     // to the sentinel for the next factorisation (a share per Schur workgroup)
     if (c.Xa)
