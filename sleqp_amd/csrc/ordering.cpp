@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 #include <queue>
 #include <thread>
@@ -245,8 +246,8 @@ struct NDState {
   std::vector<int> inset;  // stamp: vertex belongs to the current subset
   std::vector<int> level;  // BFS level / scratch
   std::vector<int> local;  // global -> local index for leaf subgraphs
-  int stamp = 0;
-  std::vector<int>& perm;
+  std::atomic<int> stamp{0};
+  std::vector<int>& perm;  // pre-sized: every call of rec() owns the slice [off, off + |verts|)
   // Leaf subgraphs are independent: the dissection only records them (vertex
   // list + the slice of the permutation they own, marked in leaf_id[]) and they
   // are ordered by minimum degree in parallel afterwards.
@@ -257,17 +258,36 @@ struct NDState {
   std::vector<LeafTask> leaves;
   std::vector<int> leaf_id;
   NDState(const Graph& g_, const NDParams& p, std::vector<int>& out)
-      : g(g_), prm(p), inset(g_.n, -1), level(g_.n, -1), local(g_.n, -1), perm(out), leaf_id(g_.n, -1) {}
-
-  void leaf(const std::vector<int>& verts) {
-    const int off = (int)perm.size();
-    const int id = (int)leaves.size();
-    for (int v : verts) {
-      perm.push_back(v);  // placeholder order, replaced by run_leaves()
-      leaf_id[v] = id;
+      : g(g_), prm(p), inset(g_.n, -1), level(g_.n, -1), local(g_.n, -1), perm(out), leaf_id(g_.n, -1) {
+    if (p.refine) {
+      side.assign(g.n, 0);
+      ext.assign(g.n, 0);
+      deg.assign(g.n, 0);
+      lockst.assign(g.n, 0);
+      mate.assign(g.n, -1);
+      hk_dist.assign(g.n, 0);
+      in_cover.assign(g.n, 0);
     }
-    if (verts.size() > 2) leaves.push_back({verts, off});
-    else leaves.push_back({std::vector<int>(), off});
+  }
+
+  // The two halves of a dissection are independent (disjoint vertex sets, disjoint slices of the
+  // permutation, unique stamps): large ones run on their own threads.
+  std::mutex leaves_mutex;
+  std::atomic<int> threads_running{1};
+  int max_threads = 1;
+
+  void leaf(const std::vector<int>& verts, int off) {
+    int id;
+    {
+      std::lock_guard<std::mutex> lock(leaves_mutex);
+      id = (int)leaves.size();
+      if (verts.size() > 2) leaves.push_back({verts, off});
+      else leaves.push_back({std::vector<int>(), off});
+    }
+    for (size_t t = 0; t < verts.size(); ++t) {
+      perm[off + t] = verts[t];  // placeholder order, replaced by run_leaves()
+      leaf_id[verts[t]] = id;
+    }
   }
 
   void order_leaf(const LeafTask& task, int id) {
@@ -348,7 +368,6 @@ struct NDState {
   // side / ext / deg are only valid for the vertices of the current subset.
   std::vector<int8_t> side;
   std::vector<int> ext, deg, lockst, mate, hk_dist;
-  int lock_stamp = 0;
 
   void move_vertex(int v, int id) {
     const int a = side[v];
@@ -368,7 +387,7 @@ struct NDState {
       bool operator<(const Ent& o) const { return gain < o.gain || (gain == o.gain && v > o.v); }
     };
     std::priority_queue<Ent> heap[2];
-    const int ls = ++lock_stamp;
+    const int ls = ++stamp;  // unique across threads; lockst[] is only compared for equality
     for (int v : verts)
       if (ext[v] > 0) heap[side[v]].push({2 * ext[v] - deg[v], v});
     std::vector<int> moved;
@@ -535,15 +554,6 @@ struct NDState {
   bool refined_cut(const std::vector<int>& order, int id, std::vector<int>& left, std::vector<int>& right,
                    std::vector<int>& sep) {
     const int k = (int)order.size();
-    if (side.empty()) {
-      side.assign(g.n, 0);
-      ext.assign(g.n, 0);
-      deg.assign(g.n, 0);
-      lockst.assign(g.n, 0);
-      mate.assign(g.n, -1);
-      hk_dist.assign(g.n, 0);
-      in_cover.assign(g.n, 0);
-    }
     int cnt[2] = {k / 2, k - k / 2};
     for (int t = 0; t < k; ++t) side[order[t]] = (int8_t)(t >= cnt[0]);
     for (int v : order) {
@@ -587,18 +597,18 @@ struct NDState {
     return small >= prm.balance * k;
   }
 
-  void rec(std::vector<int> verts) {
+  void rec(std::vector<int> verts, int off) {
     const int k = (int)verts.size();
     if (k <= prm.leaf_size) {
-      leaf(verts);
+      leaf(verts, off);
       return;
     }
     const int id = ++stamp;
     for (int v : verts) inset[v] = id;
 
-    // ---- connected components
     std::vector<int> order, lev_ptr;
-    {
+    // connected components: only looked for when the first sweep below does not reach every vertex
+    auto split_components = [&]() -> bool {
       std::vector<std::vector<int>> comps;
       const int cid = ++stamp;  // component-visited stamp
       std::vector<int> queue;
@@ -622,11 +632,17 @@ struct NDState {
       }
       if (!comps.empty()) {
         std::vector<int>().swap(verts);
-        for (auto& c : comps) rec(std::move(c));
-        return;
+        int o = off;
+        for (auto& c : comps) {
+          const int kc = (int)c.size();
+          rec(std::move(c), o);
+          o += kc;
+        }
+        return true;
       }
       for (int v : verts) inset[v] = id;
-    }
+      return false;
+    };
 
     // ---- pseudo-peripheral root
     int root = verts[0];
@@ -641,8 +657,13 @@ struct NDState {
       }
     }
     int ecc = -1;
-    for (int it = 0; it < 6; ++it) {
+    bool fresh = false;  // order / lev_ptr belong to the current root
+    for (int it = 0; it < 6; ++it) {  // (usually converges after two or three sweeps)
       bfs(root, id, order, lev_ptr);
+      fresh = true;
+      if (it == 0 && (int)order.size() < k) {
+        if (split_components()) return;
+      }
       const int nlev = (int)lev_ptr.size() - 1;
       if (nlev - 1 <= ecc) break;
       ecc = nlev - 1;
@@ -659,11 +680,12 @@ struct NDState {
       }
       if (cand == root) break;
       root = cand;
+      fresh = false;
     }
-    bfs(root, id, order, lev_ptr);
+    if (!fresh) bfs(root, id, order, lev_ptr);
     const int nlev = (int)lev_ptr.size() - 1;
     if (nlev < 3) {
-      leaf(verts);
+      leaf(verts, off);
       return;
     }
 
@@ -720,26 +742,35 @@ struct NDState {
       }
     }
     if (sep.empty() || left.empty() || right.empty() || (double)sep.size() > prm.max_sep_frac * k) {
-      leaf(verts);
+      leaf(verts, off);
       return;
     }
     std::vector<int>().swap(verts);
     std::vector<int>().swap(order);
-    rec(std::move(left));
-    rec(std::move(right));
-    for (int v : sep) perm.push_back(v);
+    const int nl = (int)left.size(), nr = (int)right.size();
+    for (size_t t = 0; t < sep.size(); ++t) perm[off + nl + nr + t] = sep[t];
+    if (std::min(nl, nr) >= 2048 && threads_running.load() < max_threads) {
+      ++threads_running;
+      std::thread other([this, &left, off] { rec(std::move(left), off); });
+      rec(std::move(right), off + nl);
+      other.join();
+      --threads_running;
+    } else {
+      rec(std::move(left), off);
+      rec(std::move(right), off + nl);
+    }
   }
 };
 
 }  // namespace
 
 void nd_order(const Graph& g, const NDParams& p, std::vector<int>& perm) {
-  perm.clear();
-  perm.reserve(g.n);
+  perm.assign(g.n, -1);
   NDState st(g, p, perm);
+  st.max_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
   std::vector<int> all(g.n);
   std::iota(all.begin(), all.end(), 0);
-  st.rec(std::move(all));
+  st.rec(std::move(all), 0);
   st.run_leaves();
   assert((int)perm.size() == g.n);
 }
