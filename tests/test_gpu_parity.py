@@ -481,6 +481,35 @@ def test_solve_sequence_with_changing_right_hand_sides(fact):
     fact.set_option("wide_min_rows", 1024)
 
 
+def test_non_finite_right_hand_side_does_not_stall_the_sweeps(fact):
+    """NaN / Inf in the right-hand side flow through the polled element exchange like any other
+    value (only the all-ones bit pattern is the sentinel, and arithmetic never produces it): no
+    timeout, non-finite output, and the next ordinary solve is exact again."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 3)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    fact.set_option("refine_steps", 0)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    b = np.random.default_rng(6).standard_normal(N)
+    fact.solve(b)
+    good = fact.solution_raw(0, N)
+    for poison in (np.nan, np.inf, -np.inf):
+        bad = b.copy()
+        bad[N - 7] = poison   # a constraint row: enters the tree at a leaf and reaches the root
+        bad[11] = poison
+        fact.solve(bad)
+        out = fact.solution_raw(0, N)
+        assert fact.info("solve_timeouts") == 0
+        assert not np.all(np.isfinite(out))
+        fact.solve(b)
+        again = fact.solution_raw(0, N)
+        assert fact.info("solve_timeouts") == 0
+        assert np.array_equal(again, good)
+    assert scaled_residual(K, good, b) <= 1e-9
+
+
 def test_pull_with_more_children_than_one_descriptor_block(fact):
     """Fronts with more than four children (amalgamation unconstrained): the gathers walk a chain of
     descriptor blocks, in child order - identical bits to the scatter kernel."""
