@@ -748,12 +748,17 @@ static int factor_enqueue(hipfact_handle* h) {
     prof_end(h);
   }
   const long long nM = (long long)P.Mi.size();
+  bool gathered = false;
   if (nM > 0) {
     if (P.saddle) {
-#define MVALS_LAUNCH(IDX, PK)                                                                                 \
-  LAUNCH(PC_MVALS, (k_mvals_prod<IDX, PK>), dim3(nblocks(nM, 1 << 16)), dim3(FB), 0, nM, h->d_prod_ptr.as<IDX>(), \
-         h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), h->d_Mtarget.as<IDX>(), h->d_Kval.as<double>(),           \
-         h->d_L.as<double>())
+      // the gather of A's values for the solves rides along in the same launch
+      const long long na = (long long)P.Ar_src.size();
+      const int nbg = na > 0 ? nblocks(na, 1 << 12) : 0;
+      gathered = na > 0;
+#define MVALS_LAUNCH(IDX, PK)                                                                                       \
+  LAUNCH(PC_MVALS, (k_mvals_prod<IDX, PK>), dim3(nblocks(nM, 1 << 16) + nbg), dim3(FB), 0, nM, h->d_prod_ptr.as<IDX>(), \
+         h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), h->d_Mtarget.as<IDX>(), h->d_Kval.as<double>(),                 \
+         h->d_L.as<double>(), na, nbg, h->d_Ar_src.as<int>(), h->d_Ar_val.as<double>())
       if (h->idx32 && h->prod_packed)
         MVALS_LAUNCH(unsigned int, true);
       else if (h->idx32)
@@ -768,7 +773,7 @@ static int factor_enqueue(hipfact_handle* h) {
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
     }
   }
-  if (P.saddle && !P.Ar_src.empty()) {
+  if (P.saddle && !P.Ar_src.empty() && !gathered) {
     const long long na = (long long)P.Ar_src.size();
     LAUNCH(PC_GATHER, k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, na, h->d_Ar_src.as<int>(),
                        h->d_Kval.as<double>(), h->d_Ar_val.as<double>());

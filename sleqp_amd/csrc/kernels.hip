@@ -64,12 +64,20 @@ template <class IDX, bool PACKED>
 __global__ __launch_bounds__(FB) void k_mvals_prod(long long nM, const IDX* __restrict__ prod_ptr,
                                                    const int* __restrict__ prod_a, const int* __restrict__ prod_b,
                                                    const IDX* __restrict__ target, const double* __restrict__ Kval,
-                                                   double* __restrict__ L) {
+                                                   double* __restrict__ L, long long ng, int nbg,
+                                                   const int* __restrict__ gsrc, double* __restrict__ gout) {
+  // the first nbg blocks carry an unrelated small job along (values of A in pivot order for the
+  // solves' SpMVs, gout[i] = Kval[gsrc[i]]): one launch and its ramp less on the critical path
+  if ((int)blockIdx.x < nbg) {
+    for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < ng; i += (long long)nbg * FB) gout[i] = Kval[gsrc[i]];
+    return;
+  }
   constexpr int CH = 64 * MV_U;
   __shared__ double2 pairs[FB / 64][CH];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double2* buf = pairs[wv];
-  for (long long e0 = blockIdx.x * (long long)FB + wv * 64; e0 < nM; e0 += (long long)gridDim.x * FB) {
+  const long long bid = blockIdx.x - nbg, nbm = gridDim.x - nbg;
+  for (long long e0 = bid * (long long)FB + wv * 64; e0 < nM; e0 += nbm * FB) {
     const long long e = e0 + lane;
     const bool valid = e < nM;
     const long long eend = (e0 + 64 < nM) ? e0 + 64 : nM;
