@@ -539,10 +539,29 @@ struct ChildWait {
   int* addr[MAXCH];
   int target[MAXCH];
   int* info;
+  // all children polled by one lane, then ONE acquire (it invalidates L2 lines) and ONE barrier
   __device__ __forceinline__ void wait() const {
+    bool any = false;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
-      if (ch < n && target[ch] > 0) flag_wait_ge(addr[ch], target[ch], info);
+    for (int ch = 0; ch < MAXCH; ++ch) any = any || (ch < n && target[ch] > 0);
+    if (!any) return;
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch)
+        if (ch < n && target[ch] > 0) {
+          int spins = 0;
+          while (__hip_atomic_load(addr[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target[ch]) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) {
+              atomicAdd(&info[INFO_TIMEOUT], 1);
+              break;
+            }
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
   }
 };
 __device__ __forceinline__ ChildWait no_wait() {
