@@ -1984,16 +1984,16 @@ __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn,
 }
 
 // ---------------------------------------------------------------------------
-// Top of the elimination tree in ONE launch per direction.  The last levels hold
-// a handful of fronts each, so a kernel per level is pure launch + dependent
-// latency.  Here every front of those levels gets its own workgroup (all of
-// them co-resident: the host caps their number far below the resident capacity),
-// and the tree dependencies are enforced with one done-flag per front:
+// The elimination tree of the solve in ONE launch per direction: every front gets its own
+// workgroup, indexed so that a front never waits for one dispatched after it (workgroups are
+// dispatched in index order, so progress needs no co-residency).  Ordinary fronts exchange their
+// vectors element by element (poll_f64 / post_f64: the data is its own flag).  Wide and generic
+// fronts use one done-flag per front:
 //   producer: all waves drain their stores, block barrier, one lane issues an
 //             agent-scope release and then a relaxed agent-scope flag store;
 //   consumer: one lane polls the flag (relaxed, agent scope, bounded spin), then
 //             an agent-scope acquire, block barrier, plain loads.
-// Flags are zeroed by a memset node before every launch.  A spin that runs out
+// The flags of one sweep are cleared by the kernel of the other.  A spin that runs out
 // sets INFO_TIMEOUT instead of hanging the GPU.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void top_wait(int* __restrict__ flags, int who, int* __restrict__ info, int target) {
