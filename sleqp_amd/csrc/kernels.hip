@@ -334,21 +334,25 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
 // lane K of its row), and it can sit on the first source of v_fmac_f64: broadcast and FMA are ONE
 // instruction of ~6.5 ns, where two ds_swizzle + FMA cost 12 ns to issue and 28 ns on a dependent
 // chain (scripts/probe/lane_exchange_latency.hip).  The compiler does not form the fused
-// instruction by itself, hence the assembly; the s_nop covers the two wait states the hardware
-// requires between a vector write of a register and its use as a DPP source (the hazard
-// recogniser does not look into inline assembly).
+// instruction by itself, hence the assembly.  Hazard: the hardware needs two wait states between a
+// vector write of a register and its use as a DPP source, and the hazard recogniser does not look
+// into inline assembly.  The statements are volatile, i.e. they stay in source order, and the source
+// order guarantees the distance for the FMAs: every register they broadcast was written by the
+// previous elimination step, at least four of these statements earlier (the four x updates close
+// every step).  Only the broadcast of the next pivot follows its producer directly; it carries
+// its own s_nop.  (An s_nop in front of every FMA costs 4 % of the whole factorisation.)
 template <int K>
 __device__ __forceinline__ double rowb_f64(double v) {
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
   return r;
 }
 // acc += (lane K of the row: src) * mul
 template <int K>
 __device__ __forceinline__ void fmac_rowb_f64(double& acc, double src, double mul) {
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc)
-      : "v"(src), "v"(mul), "n"(K));
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "n"(K));
 }
 
 // Elimination step K of the diagonal block.  Lane (i = li, q = lk) holds the WHOLE row i of the
