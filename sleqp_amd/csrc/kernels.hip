@@ -338,8 +338,8 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
 // vector write of a register and its use as a DPP source, and the hazard recogniser does not look
 // into inline assembly.  The statements are volatile, i.e. they stay in source order, and the source
 // order guarantees the distance for the FMAs: every register they broadcast was written by the
-// previous elimination step, at least four of these statements earlier (the four x updates close
-// every step).  Only the broadcast of the next pivot follows its producer directly; it carries
+// previous elimination step, at least four of these statements earlier (the x updates close every
+// step, behind an s_nop of their own).  Only the broadcast of the next pivot follows its producer directly; it carries
 // its own s_nop.  (An s_nop in front of every FMA costs 4 % of the whole factorisation.)
 template <int K>
 __device__ __forceinline__ double rowb_f64(double v) {
@@ -373,6 +373,9 @@ __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], dou
   }
 #pragma unroll
   for (int j = K + 2; j < 16; ++j) fmac_rowb_f64<K>(a[j], a[j], nl);  // columns j <= k are dead
+  // (a slice of x that is touched for the first time was initialised by compiler-generated vector
+  // code, possibly right here: two wait states, once per step)
+  asm volatile("s_nop 1");
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc)
     if (4 * cc <= K) fmac_rowb_f64<K>(x[cc], x[cc], nl);
