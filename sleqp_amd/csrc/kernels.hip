@@ -361,6 +361,10 @@ __device__ __forceinline__ void fmac_rowb_f64(double& acc, double src, double mu
 // nothing crosses the 16-lane rows, nothing goes through LDS.  X[k][j] = 0 for j > k, so the
 // slices cc > k / 4 of x are not touched yet.  nl is -l_ik of THIS step, computed at the end
 // of the previous one; the next pivot column is updated first.
+// Rows i <= k are finished: their multiplier must be zero for x (its rows are the result), but
+// their part of a is never read again (row k was broadcast in this very step, the pivots are
+// captured when they become final), so the a updates take the raw multiplier and the select
+// stays off the dependent chain.
 template <int K>
 __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], double& dsel, int li, double nl) {
   double nl_next = 0.0;
@@ -368,17 +372,17 @@ __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], dou
   dsel = (li == K + 1) ? a[K + 1] : dsel;  // pivot k + 1 is final now
   if (K < 14) {
     const double d = rowb_f64<K + 1>(a[K + 1]);
-    const double am = (li > K + 1) ? -a[K + 1] : 0.0;  // rows i <= k + 1 are finished
-    nl_next = am * fast_rcp(d);
+    nl_next = -a[K + 1] * fast_rcp(d);
   }
 #pragma unroll
   for (int j = K + 2; j < 16; ++j) fmac_rowb_f64<K>(a[j], a[j], nl);  // columns j <= k are dead
+  const double nlx = (li > K) ? nl : 0.0;
   // (a slice of x that is touched for the first time was initialised by compiler-generated vector
-  // code, possibly right here: two wait states, once per step)
+  // code, and nlx is selected right here: two wait states, once per step)
   asm volatile("s_nop 1");
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc)
-    if (4 * cc <= K) fmac_rowb_f64<K>(x[cc], x[cc], nl);
+    if (4 * cc <= K) fmac_rowb_f64<K>(x[cc], x[cc], nlx);
   return nl_next;
 }
 
@@ -401,8 +405,7 @@ __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratc
   double nl;
   {
     const double d = rowb_f64<0>(a[0]);
-    const double am = (li > 0) ? -a[0] : 0.0;
-    nl = am * fast_rcp(d);
+    nl = -a[0] * fast_rcp(d);
   }
   nl = diag_step<0>(a, x, dsel, li, nl);
   nl = diag_step<1>(a, x, dsel, li, nl);
