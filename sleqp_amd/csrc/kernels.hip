@@ -341,6 +341,7 @@ __device__ __forceinline__ void dev_assemble(const SnDesc& S, const FrontCtx& c,
 // previous elimination step, at least four of these statements earlier (the x updates close every
 // step, behind an s_nop of their own).  Only the broadcast of the next pivot follows its producer directly; it carries
 // its own s_nop.  (An s_nop in front of every FMA costs 4 % of the whole factorisation.)
+// tests/test_isa_hazards.py checks the distances in the compiled code.
 template <int K>
 __device__ __forceinline__ double rowb_f64(double v) {
   double r;
