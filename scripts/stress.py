@@ -1,0 +1,69 @@
+"""Randomised stress run on the GPU (not part of the test suite): shapes from tiny to mid-size,
+both generators, active bounds, random schedule options, repeated solves and refactorisations with
+changed values; every solution is checked through the scaled residual of K.  Usage:
+    python scripts/stress.py [seconds] [seed] [log10 of the smallest n]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+from sleqp_amd import synth  # noqa: E402
+from sleqp_amd.fact import HipFact  # noqa: E402
+from sleqp_amd.sparse import SleqpMat  # noqa: E402
+from util import scaled_residual  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fact = HipFact(device=0)
+t0, trials, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    kind = rng.choice(["b", "u"])
+    lo = float(sys.argv[3]) if len(sys.argv) > 3 else 1.2
+    n = int(10 ** rng.uniform(lo, 4.6 if kind == "b" else max(lo + 0.1, 3.6)))
+    m = int(max(1, n * rng.uniform(0.05, 0.6)))
+    per_row = int(rng.integers(2, 24))
+    J = (synth.banded_jacobian(n, m, per_row, int(rng.integers(per_row + 1, 400)), int(rng.integers(1 << 30))) if kind == "b"
+         else synth.uniform_jacobian(n, m, min(per_row, 12), int(rng.integers(1 << 30))))
+    vi, ci, W = synth.working_set_all_rows(n, m, float(rng.choice([0.0, 0.0, 0.1])), int(rng.integers(1 << 30)))
+    if W > n:
+        continue
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    opts = {"factor_top_max": int(rng.choice([128, 128, 0, 8, 400])), "pull_max_children": int(rng.choice([4, 4, 0])),
+            "top_max_fronts": int(rng.choice([1024, 1024, 0, 64])), "wide_min_rows": int(rng.choice([1024, 200])),
+            "refine_steps": int(rng.choice([0, 1])), "use_graph": int(rng.choice([0, 1, 1]))}
+    for k, v in opts.items():
+        fact.set_option(k, v)
+    try:
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    except Exception as e:  # numerically dependent working sets are legitimate failures
+        if "singular" in str(e):
+            continue
+        raise
+    for rep in range(int(rng.integers(1, 4))):
+        if rep == 1:  # same pattern, new values: numeric refactorisation
+            kd = kd.copy()
+            off = kd != 1.0
+            kd[off] *= rng.uniform(0.5, 2.0, size=int(off.sum()))
+            K = synth.kkt_full_matrix(N, kc, kr, kd)
+            try:
+                fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            except Exception as e:
+                if "singular" in str(e):
+                    break
+                raise
+        b = rng.standard_normal(N) * 10.0 ** rng.integers(-2, 3)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        res = scaled_residual(K, z, b)
+        worst = max(worst, res)
+        tol = 1e-10 if opts["refine_steps"] else 1e-7
+        assert np.all(np.isfinite(z)) and res <= tol, (kind, n, m, per_row, W, opts, rep, res)
+        assert fact.info("solve_timeouts") == 0
+    trials += 1
+print(f"stress: {trials} problems in {time.time() - t0:.0f} s, worst scaled residual {worst:.2e}")
