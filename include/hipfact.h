@@ -103,6 +103,15 @@ int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol);
 /* Device pointer to the last solution (N doubles, owned by the handle). */
 int hipfact_solution_device(hipfact_handle* h, const double** d_sol);
 
+/* Blocks until the queued work has finished and reports what the asynchronous
+ * entry points above could not: a singular / rank-deficient factorisation
+ * (HIPFACT_ESINGULAR), a solve whose iterative refinement stalled far above its
+ * tolerance (HIPFACT_ESINGULAR, "numerically singular"), a dependency wait that
+ * timed out inside a single-launch kernel (HIPFACT_EINTERNAL; the handle is put
+ * back into a clean state and needs a new factorisation).  A refinement that
+ * needs more passes than the solve graph carries is continued here. */
+int hipfact_check(hipfact_handle* h);
+
 /* Blocks until all work queued on the handle's stream has finished. */
 int hipfact_synchronize(hipfact_handle* h);
 
@@ -177,8 +186,17 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
 /* ---- options / introspection ------------------------------------------- */
 
 /* Options.
- *   numerics:  "refine_steps" (iterative-refinement steps per solve, default 1),
- *              "refine_adaptive", "refine_tol";
+ *   numerics:  "refine_steps" (correction passes carried by every solve graph,
+ *              default 1, 0 = plain solve without residual; the passes return at
+ *              once when the device-side control block reports convergence),
+ *              "refine_max" (total passes including those continued by
+ *              hipfact_solution / hipfact_check, default 10), "refine_tol"
+ *              (forward-error target, default 1e-10: the backward-error
+ *              tolerance is refine_tol / condition estimate, clamped to
+ *              [4.5e-16, 1e-12]), "refine_adaptive" (0: every in-graph pass
+ *              runs), "fail_omega" (a solve that stalls above this backward
+ *              error is reported as singular, default 1e-8), "equilibrate"
+ *              (row equilibration of the constraint block, default 1);
  *   analysis (take effect at the next set_matrix / assemble, which re-analyses):
  *              "ordering" (0 nested dissection, 1 AMD, 2 natural), "wmax"
  *              (widest supernode, default 128), "max_children" (amalgamation
@@ -199,7 +217,9 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
  * Unknown names return HIPFACT_EINVAL. */
 int hipfact_set_option(hipfact_handle* h, const char* name, double value);
 
-/* Info: "N", "n", "m", "saddle", "nnzK", "nnzL", "nnzL_true", "flops",
+/* Info (of the last finished solve: "last_omega" backward error in the
+ * equilibrated space, "last_iters", "last_status" 0 converged / 1 stalled /
+ * 2 non-finite / 3 pass limit, "kappa_est"); "N", "n", "m", "saddle", "nnzK", "nnzL", "nnzL_true", "flops",
  * "flops_dense", "nsuper", "nlevels", "nprod", "L_bytes", "U_bytes",
  * "analysis_s", "num_perturbed", "cache_hits", "max_r", "max_w",
  * "solve_bytes", "factor_bytes", ... */

@@ -89,5 +89,7 @@ constexpr int TOP_L21_CAP = 16384;  // doubles of L21 (forward) / inv(L11) (back
 
 // info words written by the factorisation kernels
 enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_TIMEOUT = 2, INFO_WORDS = 4 };
+// ... followed by two 64-bit words: pivot minimum (bit-inverted) and maximum (k_pivot_minmax)
+constexpr int INFO_BYTES = INFO_WORDS * 4 + 16;
 
 }  // namespace hipfact

@@ -206,8 +206,11 @@ __device__ __forceinline__ double poll_f64(const double* __restrict__ p, int* __
   return __longlong_as_double((long long)bits);
 }
 __device__ __forceinline__ void post_f64(double* __restrict__ p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a NaN that carries the sentinel's payload (a caller's right-hand side may hold any bit pattern, and
+  // NaN payloads propagate through arithmetic) is posted as the canonical quiet NaN instead
+  unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  bits = (bits == SOLVE_SENT) ? 0x7FF8000000000000ull : bits;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void sent_f64(double* __restrict__ p) {
   *reinterpret_cast<unsigned long long*>(p) = SOLVE_SENT;
@@ -818,6 +821,28 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         c.P[row + (long long)col * r] = -xpend[q];
         if (c.Xa) post_f64(c.Xa + row + col * c.wp, -xpend[q]);
       }
+    }
+  }
+  // Pivot range of the front (condition estimate, refinement tolerance): behind the info words,
+  // word 0 = max over ~bits(|d|) (the minimum), word 1 = max over bits(|d|), both zeroed with them.
+  // Bit patterns of non-negative doubles order like the values, so integer atomics do, in any
+  // order of arrival.  One wave that is off the chain, two atomics without return value.
+  if (wave == nw - 1 && !(phases & 32)) {
+    double lo = 1.7e308, hi = 0.0;
+    for (int k = lane; k < w; k += 64) {
+      const double d = fabs(dd[k]);
+      lo = fmin(lo, d);
+      hi = fmax(hi, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = fmin(lo, __shfl_down(lo, o, 64));
+      hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if (lane == 0) {
+      unsigned long long* mm = reinterpret_cast<unsigned long long*>(info + INFO_WORDS);
+      atomicMax(&mm[0], ~(unsigned long long)__double_as_longlong(lo));
+      atomicMax(&mm[1], (unsigned long long)__double_as_longlong(hi));
     }
   }
   if (ROWINV) __syncthreads();
@@ -1733,8 +1758,9 @@ __device__ __forceinline__ void dev_fwd_front_top(const TopItem& T, const double
 __global__ __launch_bounds__(SB) void k_fwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rel,
                                                   const int* __restrict__ child_idx, double* __restrict__ y,
-                                                  double* __restrict__ uvec) {
+                                                  double* __restrict__ uvec, const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (skip && *skip) return;
   const SnDesc S = sn[level_sn[blockIdx.x]];
   dev_fwd_front(S, sn, L, rel, child_idx, y, uvec, lds);
 }
@@ -1985,8 +2011,9 @@ __device__ __forceinline__ void dev_bwd_small(long long Loff, long long rowoff, 
 
 __global__ __launch_bounds__(SB) void k_bwd_level(const SnDesc* __restrict__ sn, const int* __restrict__ level_sn,
                                                   const double* __restrict__ L, const int* __restrict__ rows,
-                                                  double* __restrict__ y) {
+                                                  double* __restrict__ y, const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (skip && *skip) return;
   const SnDesc S = sn[level_sn[blockIdx.x]];
   if (S.r - S.w <= 256)
     dev_bwd_small<false>(S.Loff, S.rowoff, S.c0, S.w, S.r, S.parent, L, rows, y, lds, nullptr, nullptr);
@@ -2391,8 +2418,9 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
                                                 double* __restrict__ y, double* __restrict__ uvec,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
                                                 int* __restrict__ info, int* __restrict__ stale, int nstale,
-                                                double* __restrict__ ysol) {
+                                                double* __restrict__ ysol, const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (skip && *skip) return;  // whole launch (and the backward one with it): the slot / flag state stays consistent
   // the flags of the opposite sweep are idle while this kernel runs: clear them for its next launch
   for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   const TopItem& T = titems[blockIdx.x];
@@ -2430,8 +2458,10 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
                                                 double* __restrict__ y, double* __restrict__ wpart,
                                                 int* __restrict__ flags, int* __restrict__ hflags,
                                                 int* __restrict__ info, int* __restrict__ stale, int nstale,
-                                                double* __restrict__ ysol, double* __restrict__ uvec) {
+                                                double* __restrict__ ysol, double* __restrict__ uvec,
+                                                const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (skip && *skip) return;
   for (int i = blockIdx.x * SB + threadIdx.x; i < nstale; i += gridDim.x * SB) stale[i] = 0;
   // parents before children: workgroups are dispatched in index order, so a front never waits
   // for one that has not been dispatched yet (no co-residency assumption for correctness)
@@ -2462,87 +2492,369 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
 
 // ---------------------------------------------------------------------------
 // Saddle-point front / back end: K = [I A^T; A 0].
-//   t_p  = A_p b_x - b_y[perm]          (right-hand side of S y = t)
-//   z_x  = b_x - A^T y ;  z_y = y       (back substitution of the leaf columns)
-//   res  = b - K z                      (iterative refinement)
-// A_p is the CSR of A with rows in pivot order; the x update walks the columns
+//
+// Internally the constraint rows are EQUILIBRATED: A^ = D A with D = diag(2^-e_k), |row k of A^| in
+// [0.7, 1.42) (powers of two: every scaling below is exact), S^ = A^ A^^T has a unit-order
+// diagonal, y^ = D^-1 y.  MA57, the reference's indefinite backend, scales by default as well
+// (fact_ma57.c:743 keeps ICNTL(15) of ma57id_).  With unit rows cond(S^) and cond(K^) agree up to
+// ||A^||^2 <= max row overlap, so the x-before-y pivot order loses nothing against a pivoted
+// factorisation of K^ once the solve is refined on K itself.
+//
+//   t_p  = A^_p b~_x - D b_y[perm]      (right-hand side of S^ y^ = t)
+//   z_x  = b~_x - A^^T y^ ;  z_y = D y^  (back substitution of the leaf columns)
+//   res  = b - K z                       (iterative refinement; norms in the equilibrated space)
+// A^_p is the CSR of A^ with rows in pivot order; the x update walks the columns
 // of K itself (its CSC arrays are the CSR of A^T).
+//
+// Working-set maps (device assembly with a cached superset plan, hipfact_assemble_kkt): the
+// factorised structure covers the constraint rows of a SUPERSET of the working set and never
+// contains the unit rows of active bounds.  SaddleMaps translates between the caller's vectors
+// (length n + |W|, working-set numbering) and that structure:
+//   cmap[s]  position of structure row s in the caller's vectors, -1: row not in the working set
+//            (its values are zero, its pivot is 1, its multiplier 0)
+//   vmap[j]  position of the unit row of the active bound of x_j, -1: bound inactive.
+// An active bound x_j = beta is eliminated exactly: b~_j = beta replaces b_j in the products, the
+// Schur complement is formed without column j (Kprod), and afterwards x_j = beta,
+// y_bound = b_j - beta - (A^T y)_j.  Both maps null: the structure IS the caller's K.
 // ---------------------------------------------------------------------------
+struct SaddleMaps {
+  const int* __restrict__ vmap;
+  const int* __restrict__ cmap;
+  const double* __restrict__ dscale;  // per pivot position
+  int n;
+};
+__device__ __forceinline__ int ext_row(const SaddleMaps& M, int s) { return M.cmap ? M.cmap[s] : M.n + s; }
+
+// Device-side control block of the iterative refinement (no host round trip per solve): written
+// by the last block of every residual kernel, read by the kernels of the correction passes,
+// which return at once when `done` is set.
+struct RefineCtl {
+  int done;     // 1: stop (converged, stagnated or non-finite)
+  int iters;    // correction passes applied so far
+  int status;   // 0 converged, 1 stagnated above the tolerance, 2 non-finite residual, 3 still running
+  int counter;  // blocks that have delivered their partial maxima (last-block election)
+  int seq;      // number of solves whose first residual has been judged (lets the host match a copy to a solve)
+  int pad;
+  double omega;       // ||r^||_inf / (||z^||_inf + ||b^||_inf), equilibrated space
+  double omega_prev;
+  double tol;         // effective tolerance of this solve
+  double kappa;       // pivot-ratio condition estimate used for it
+};
+
 // 16 lanes per row (rows of A hold ~20 entries in the headline configuration):
 // consecutive lanes read consecutive entries, fixed shuffle tree => deterministic.
 constexpr int RL = 16;
-__global__ __launch_bounds__(FB) void k_rhs_saddle(int m, int n, const int* __restrict__ Ar_ptr,
-                                                   const int* __restrict__ Ar_col, const double* __restrict__ Ar_val,
-                                                   const int* __restrict__ perm, const double* __restrict__ b,
-                                                   double* __restrict__ t) {
+
+// Row equilibration, values of A^ in pivot order (Ar_val), and the scaled copy of K's values in K's
+// own order: Ksc for the x update, Kprod for the Schur-complement products (the same array unless
+// there are active bounds, whose columns do not enter the products).  Every off-diagonal entry of
+// a column < n of K belongs to exactly one row of A, so the scatter through Ar_src covers them
+// all (the unit diagonal is never read).  norm^2 is taken over the columns that enter the products.
+// The first nbz blocks carry the zero fill of the factor arena (and of the info words) along: this
+// kernel is bound by dependent gathers and leaves the memory system idle, the fill is pure
+// bandwidth, and as two graph nodes they would run one after the other on the critical path.
+__global__ __launch_bounds__(FB) void k_row_scale(int m, const int* __restrict__ Ar_ptr,
+                                                  const int* __restrict__ Ar_col, const int* __restrict__ Ar_src,
+                                                  const double* __restrict__ Kval, const int* __restrict__ vmap,
+                                                  int enable, double* __restrict__ dscale,
+                                                  double* __restrict__ Ar_val, double* __restrict__ Ksc,
+                                                  double* __restrict__ Kprod, int nbz, double2* __restrict__ zero,
+                                                  long long nzero, int* __restrict__ info) {
+  if ((int)blockIdx.x < nbz) {
+    if (blockIdx.x == 0 && threadIdx.x < INFO_BYTES / 4) info[threadIdx.x] = 0;
+    const double2 z = {0.0, 0.0};
+    for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < nzero; i += (long long)nbz * FB) zero[i] = z;
+    return;
+  }
   const int sub = threadIdx.x % RL;
   const int rpb = FB / RL;
-  for (int k = blockIdx.x * rpb + threadIdx.x / RL; k < m; k += gridDim.x * rpb) {
+  const int nbw = gridDim.x - nbz, bid = blockIdx.x - nbz;
+  const int iters = (m + nbw * rpb - 1) / (nbw * rpb);
+  for (int it = 0; it < iters; ++it) {  // uniform trip count (the shuffles need whole groups)
+    const int k = (it * nbw + bid) * rpb + threadIdx.x / RL;
     double s = 0.0;
-    const int p1 = Ar_ptr[k + 1];
-    for (int p = Ar_ptr[k] + sub; p < p1; p += RL) s += Ar_val[p] * b[Ar_col[p]];
+    int p0 = 0, p1 = 0;
+    constexpr int KEEP = 4;  // rows of up to 64 entries are read once
+    double v[KEEP];
+    int src[KEEP];
+    bool fx[KEEP];
+    if (k < m) {
+      p0 = Ar_ptr[k];
+      p1 = Ar_ptr[k + 1];
+      int q = 0;
+      for (int p = p0 + sub; p < p1; p += RL, ++q) {
+        const int e = Ar_src[p];
+        const double val = Kval[e];
+        const bool fixed = vmap && vmap[Ar_col[p]] >= 0;
+        if (q < KEEP) {
+          v[q] = val;
+          src[q] = e;
+          fx[q] = fixed;
+        }
+        if (!fixed) s += val * val;
+      }
+    }
 #pragma unroll
     for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
-    if (sub == 0) t[k] = s - b[n + perm[k]];
+    s = __shfl(s, 0, RL);
+    double d = 1.0;
+    if (enable && s > 0.0 && s < 1.7e308) {
+      int e;
+      (void)frexp(s, &e);         // s = f 2^e, f in [0.5, 1)
+      d = ldexp(1.0, -(e >> 1));  // d^2 s in [0.5, 2)
+    }
+    if (k < m) {
+      if (sub == 0) dscale[k] = d;
+      int q = 0;
+      for (int p = p0 + sub; p < p1; p += RL, ++q) {
+        int e;
+        double val;
+        bool fixed;
+        if (q < KEEP) {
+          e = src[q];
+          val = v[q];
+          fixed = fx[q];
+        } else {
+          e = Ar_src[p];
+          val = Kval[e];
+          fixed = vmap && vmap[Ar_col[p]] >= 0;
+        }
+        val *= d;
+        Ar_val[p] = val;
+        Ksc[e] = val;
+        if (Kprod != Ksc) Kprod[e] = fixed ? 0.0 : val;
+      }
+    }
   }
 }
 
 // 8 lanes per column of K (columns hold ~11 entries)
 constexpr int CL = 8;
+
+// rows of the superset that are not in the working set: unit pivot (their row of A is zero)
+__global__ __launch_bounds__(FB) void k_diag_inactive(int m, const int* __restrict__ perm,
+                                                      const int* __restrict__ cmap,
+                                                      const long long* __restrict__ diag_target,
+                                                      double* __restrict__ L) {
+  for (int k = blockIdx.x * FB + threadIdx.x; k < m; k += gridDim.x * FB)
+    if (cmap[perm[k]] < 0) L[diag_target[k]] = 1.0;
+}
+
+__global__ __launch_bounds__(FB) void k_rhs_saddle(int m, const int* __restrict__ Ar_ptr,
+                                                   const int* __restrict__ Ar_col, const double* __restrict__ Ar_val,
+                                                   const int* __restrict__ perm, SaddleMaps M,
+                                                   const double* __restrict__ b, double* __restrict__ t,
+                                                   const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int sub = threadIdx.x % RL;
+  const int rpb = FB / RL;
+  for (int k = blockIdx.x * rpb + threadIdx.x / RL; k < m; k += gridDim.x * rpb) {
+    double s = 0.0;
+    const int p1 = Ar_ptr[k + 1];
+    if (M.vmap) {
+      for (int p = Ar_ptr[k] + sub; p < p1; p += RL) {
+        const int j = Ar_col[p], v = M.vmap[j];
+        s += Ar_val[p] * b[v >= 0 ? v : j];
+      }
+    } else {
+      for (int p = Ar_ptr[k] + sub; p < p1; p += RL) s += Ar_val[p] * b[Ar_col[p]];
+    }
+#pragma unroll
+    for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
+    if (sub == 0) {
+      const int i = ext_row(M, perm[k]);
+      t[k] = i >= 0 ? s - b[i] * M.dscale[k] : 0.0;
+    }
+  }
+}
+
+// ACC: z += (correction pass) instead of z =
+template <bool ACC>
 __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __restrict__ Kp,
-                                                 const double* __restrict__ Kval, const int* __restrict__ Kc_y,
-                                                 const int* __restrict__ perm, const double* __restrict__ yp,
-                                                 const double* __restrict__ b, double* __restrict__ z) {
+                                                 const double* __restrict__ Ksc, const int* __restrict__ Kc_y,
+                                                 const int* __restrict__ perm, SaddleMaps M,
+                                                 const double* __restrict__ yp, const double* __restrict__ b,
+                                                 double* __restrict__ z, const int* __restrict__ skip) {
+  if (skip && *skip) return;
   const int sub = threadIdx.x % CL;
   const int cpb = FB / CL;
   for (int j = blockIdx.x * cpb + threadIdx.x / CL; j < n; j += gridDim.x * cpb) {
     double s = 0.0;
     const int e1 = Kp[j + 1];
-    for (int e = Kp[j] + 1 + sub; e < e1; e += CL) s += Kval[e] * yp[Kc_y[e]];
+    for (int e = Kp[j] + 1 + sub; e < e1; e += CL) s += Ksc[e] * yp[Kc_y[e]];
 #pragma unroll
     for (int o = CL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, CL);
-    if (sub == 0) z[j] = b[j] - s;
+    if (sub == 0) {
+      const int v = M.vmap ? M.vmap[j] : -1;
+      if (v >= 0) {
+        const double beta = b[v];
+        const double mult = (b[j] - beta) - s;
+        if (ACC) {
+          z[j] += beta;
+          z[v] += mult;
+        } else {
+          z[j] = beta;
+          z[v] = mult;
+        }
+      } else if (ACC) {
+        z[j] += b[j] - s;
+      } else {
+        z[j] = b[j] - s;
+      }
+    }
   }
-  for (int k = blockIdx.x * FB + threadIdx.x; k < m; k += gridDim.x * FB) z[n + perm[k]] = yp[k];
+  for (int k = blockIdx.x * FB + threadIdx.x; k < m; k += gridDim.x * FB) {
+    const int i = ext_row(M, perm[k]);
+    if (i >= 0) {
+      const double v = yp[k] * M.dscale[k];
+      if (ACC)
+        z[i] += v;
+      else
+        z[i] = v;
+    }
+  }
 }
 
-// max-norm partials for the refinement check: one (max |res|, max |b|) pair per
-// block, reduced on the host after the (tiny) copy back; no atomics, no extra
-// kernel.  A NaN residual propagates (it must force the correction / error path).
-__device__ __forceinline__ void norms_store(double r, double b, double* __restrict__ norms) {
-  __shared__ double sr[FB / 64], sb[FB / 64];
+// ---- refinement control ---------------------------------------------------------------------
+// Every block of a residual kernel leaves (max |r^|, max |b^|, max |z^|); the block that arrives
+// last reduces them and decides.  A NaN residual propagates (it must end the loop).
+//   tol = clamp(target / kappa, 4.5e-16, 1e-12), kappa = 10 max|d| / min|d| of the pivots: the
+//   forward error of a solve with backward error omega is about kappa omega, so well conditioned
+//   systems are accepted after the first pass and ill conditioned ones are refined to the limit.
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+
+__device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, RefineCtl* __restrict__ hctl,
+                                              double* __restrict__ partials, int first, double target,
+                                              const unsigned long long* __restrict__ minmax, double mr, double mb,
+                                              double mz) {
+  __shared__ double sh[3][FB / 64];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const double vr = __shfl_down(r, o, 64), vb = __shfl_down(b, o, 64);
-    r = (vr > r || vr != vr) ? vr : r;
-    b = fmax(b, vb);
+    mr = nanmax(mr, __shfl_down(mr, o, 64));
+    mb = nanmax(mb, __shfl_down(mb, o, 64));
+    mz = nanmax(mz, __shfl_down(mz, o, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
-    sr[threadIdx.x >> 6] = r;
-    sb[threadIdx.x >> 6] = b;
+  if ((tid & 63) == 0) {
+    sh[0][tid >> 6] = mr;
+    sh[1][tid >> 6] = mb;
+    sh[2][tid >> 6] = mz;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  // No fences (an agent-scope release writes back the dirty lines of L2, an acquire invalidates
+  // them): the partials travel as agent-scope atomic stores / loads, which operate on L2 itself, and
+  // the ticket is taken after the stores have been acknowledged.
+  if (tid == 0) {
     for (int q = 1; q < FB / 64; ++q) {
-      r = (sr[q] > r || sr[q] != sr[q]) ? sr[q] : r;
-      b = fmax(b, sb[q]);
+      mr = nanmax(mr, sh[0][q]);
+      mb = nanmax(mb, sh[1][q]);
+      mz = nanmax(mz, sh[2][q]);
     }
-    norms[2 * blockIdx.x] = r;
-    norms[2 * blockIdx.x + 1] = b;
+    __hip_atomic_store(&partials[3 * blockIdx.x], mr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[3 * blockIdx.x + 1], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[3 * blockIdx.x + 2], mz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (ticket == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double r = 0.0, bb = 0.0, zz = 0.0;
+  {
+    constexpr int PU = 8;  // resid grids hold at most 2048 blocks
+    double pr[PU], pb[PU], pz[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int q = tid + u * FB;
+      const bool in = q < (int)gridDim.x;
+      pr[u] = in ? __hip_atomic_load(&partials[3 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      pb[u] = in ? __hip_atomic_load(&partials[3 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      pz[u] = in ? __hip_atomic_load(&partials[3 * q + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      r = nanmax(r, pr[u]);
+      bb = nanmax(bb, pb[u]);
+      zz = nanmax(zz, pz[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r = nanmax(r, __shfl_down(r, o, 64));
+    bb = nanmax(bb, __shfl_down(bb, o, 64));
+    zz = nanmax(zz, __shfl_down(zz, o, 64));
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    sh[0][tid >> 6] = r;
+    sh[1][tid >> 6] = bb;
+    sh[2][tid >> 6] = zz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = 1; q < FB / 64; ++q) {
+      r = nanmax(r, sh[0][q]);
+      bb = nanmax(bb, sh[1][q]);
+      zz = nanmax(zz, sh[2][q]);
+    }
+    const double lo = __longlong_as_double((long long)~minmax[0]), hi = __longlong_as_double((long long)minmax[1]);
+    const double kappa = (minmax[1] == 0ull) ? 10.0 : ((lo > 0.0 && hi >= lo) ? 10.0 * hi / lo : 1e300);
+    const double tol = fmin(1e-12, fmax(4.5e-16, target / kappa));
+    const double den = zz + bb;
+    const double omega = (r == 0.0) ? 0.0 : r / den;  // den == 0 with r != 0 cannot happen; NaN stays NaN
+    const int iters = first ? 0 : ctl->iters + 1;
+    const int seq = ctl->seq + (first ? 1 : 0);
+    const double prev = first ? 1.7e308 : ctl->omega;
+    int done = 0, status = 3;
+    if (!(omega == omega) || !(den < 1.7e308)) {
+      done = 1;
+      status = 2;
+    } else if (target < 0.0) {
+      // non-adaptive mode: the passes of the graph run unconditionally
+    } else if (omega <= tol) {
+      done = 1;
+      status = 0;
+    } else if (!first && omega > 0.5 * prev) {
+      done = 1;
+      status = 1;
+    }
+    ctl->iters = iters;
+    ctl->omega_prev = prev;
+    ctl->omega = omega;
+    ctl->tol = tol;
+    ctl->kappa = kappa;
+    ctl->status = status;
+    ctl->seq = seq;
+    __hip_atomic_store(&ctl->counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl->done = done;  // read by the kernels of the next pass: a kernel boundary away
+    // copy for the host in pinned memory (visible after the stream has been synchronised): no copy node
+    hctl->iters = iters;
+    hctl->omega_prev = prev;
+    hctl->omega = omega;
+    hctl->tol = tol;
+    hctl->kappa = kappa;
+    hctl->status = status;
+    hctl->done = done;
+    __hip_atomic_store(&hctl->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // last: the host may peek without a sync
   }
 }
 
-// res = b - K z for the saddle matrix (columns < n of the lower CSC hold I and A).
-// Two sweeps with cooperative lanes (8 per column of K, 16 per row of A), block
-// partial max-norms for the refinement check.
+// res = b - K z for the saddle matrix (columns < n of the lower CSC hold I and A), in the caller's
+// numbering.  Two sweeps with cooperative lanes (8 per column of K, 16 per row of A); the last
+// block updates the refinement control block (ctl null: plain residual).
 __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int* __restrict__ Kp,
                                                         const int* __restrict__ Ki, const double* __restrict__ Kval,
                                                         const int* __restrict__ Ar_ptr, const int* __restrict__ Ar_col,
                                                         const double* __restrict__ Ar_val,
-                                                        const int* __restrict__ perm, const double* __restrict__ b,
-                                                        const double* __restrict__ z, double* __restrict__ res,
-                                                        double* __restrict__ norms) {
-  double mr = 0.0, mb = 0.0;
+                                                        const int* __restrict__ perm, SaddleMaps M,
+                                                        const double* __restrict__ b, const double* __restrict__ z,
+                                                        double* __restrict__ res, RefineCtl* __restrict__ ctl,
+                                                        RefineCtl* __restrict__ hctl, double* __restrict__ partials,
+                                                        int first, double target,
+                                                        const unsigned long long* __restrict__ minmax) {
+  if (ctl && !first && ctl->done) return;
+  double mr = 0.0, mb = 0.0, mz = 0.0;
   {
     const int sub = threadIdx.x % CL;
     const int cpb = FB / CL;
@@ -2552,16 +2864,31 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
       double s = 0.0;
       if (j < n) {
         const int e1 = Kp[j + 1];
-        for (int e = Kp[j] + sub; e < e1; e += CL) s += Kval[e] * z[Ki[e]];
+        for (int e = Kp[j] + sub; e < e1; e += CL) {
+          const int i = Ki[e];
+          const int zi = i < n ? i : ext_row(M, i - n);
+          if (zi >= 0) s += Kval[e] * z[zi];
+        }
       }
 #pragma unroll
       for (int o = CL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, CL);
       if (sub == 0 && j < n) {
-        const double bj = b[j];
+        const double bj = b[j], zj = z[j];
+        const int v = M.vmap ? M.vmap[j] : -1;
+        if (v >= 0) {  // unit row of the active bound: multiplier z[v] in row j, and its own row x_j = b_v
+          const double zv = z[v], bv = b[v];
+          s += zv;
+          const double rv = bv - zj;
+          res[v] = rv;
+          mr = nanmax(mr, fabs(rv));
+          mb = fmax(mb, fabs(bv));
+          mz = fmax(mz, fabs(zv));
+        }
         const double rj = bj - s;
         res[j] = rj;
-        mr = (fabs(rj) > mr || rj != rj) ? fabs(rj) : mr;
+        mr = nanmax(mr, fabs(rj));
         mb = fmax(mb, fabs(bj));
+        mz = fmax(mz, fabs(zj));
       }
     }
   }
@@ -2579,16 +2906,20 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
 #pragma unroll
       for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
       if (sub == 0 && k < m) {
-        const int i = n + perm[k];
-        const double bi = b[i];
-        const double ri = bi - s;
-        res[i] = ri;
-        mr = (fabs(ri) > mr || ri != ri) ? fabs(ri) : mr;
-        mb = fmax(mb, fabs(bi));
+        const int i = ext_row(M, perm[k]);
+        if (i >= 0) {
+          const double d = M.dscale[k];
+          const double bi = b[i] * d;  // equilibrated row
+          const double ri = bi - s;
+          res[i] = ri / d;
+          mr = nanmax(mr, fabs(ri));
+          mb = fmax(mb, fabs(bi));
+          mz = fmax(mz, fabs(z[i] / d));
+        }
       }
     }
   }
-  if (norms) norms_store(mr, mb, norms);
+  if (ctl) refine_decide(ctl, hctl, partials, first, target, minmax, mr, mb, mz);
 }
 
 // Generic mode residual: res = b - (L + L^T - diag) z with L lower CSC and its
@@ -2597,9 +2928,12 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
                                                      const double* __restrict__ Kval, const int* __restrict__ Tp,
                                                      const int* __restrict__ Ti, const int* __restrict__ Tsrc,
                                                      const double* __restrict__ b, const double* __restrict__ z,
-                                                     double* __restrict__ res,
-                                                     double* __restrict__ norms) {
-  double mr = 0.0, mb = 0.0;
+                                                     double* __restrict__ res, RefineCtl* __restrict__ ctl,
+                                                     RefineCtl* __restrict__ hctl, double* __restrict__ partials,
+                                                     int first, double target,
+                                                     const unsigned long long* __restrict__ minmax) {
+  if (ctl && !first && ctl->done) return;
+  double mr = 0.0, mb = 0.0, mz = 0.0;
   const int iters = (N + gridDim.x * FB - 1) / (gridDim.x * FB);
   for (int it = 0; it < iters; ++it) {
     const int j = (it * gridDim.x + blockIdx.x) * FB + threadIdx.x;
@@ -2610,15 +2944,18 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
       for (int p = Tp[j]; p < Tp[j + 1]; ++p)                            // row j: columns < j
         if (Ti[p] != j) s -= Kval[Tsrc[p]] * z[Ti[p]];
       res[j] = s;
-      mr = (fabs(s) > mr || s != s) ? fabs(s) : mr;
+      mr = nanmax(mr, fabs(s));
       mb = fmax(mb, fabs(bj));
+      mz = fmax(mz, fabs(z[j]));
     }
   }
-  if (norms) norms_store(mr, mb, norms);
+  if (ctl) refine_decide(ctl, hctl, partials, first, target, minmax, mr, mb, mz);
 }
 
+// y += a x, or nothing when *skip is set
 __global__ __launch_bounds__(FB) void k_axpy(long long n, double a, const double* __restrict__ x,
-                                             double* __restrict__ y) {
+                                             double* __restrict__ y, const int* __restrict__ skip) {
+  if (skip && *skip) return;
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
     y[i] += a * x[i];
 }
@@ -2670,39 +3007,26 @@ __global__ __launch_bounds__(FB) void k_scatter(long long n, const int* __restri
     out[idx[i]] = in[i];
 }
 
+// generic mode, correction passes: gather / scatter-accumulate unless *skip is set
+__global__ __launch_bounds__(FB) void k_gather_skip(long long n, const int* __restrict__ src,
+                                                    const double* __restrict__ in, double* __restrict__ out,
+                                                    const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
+    out[i] = in[src[i]];
+}
+__global__ __launch_bounds__(FB) void k_scatter_acc(long long n, const int* __restrict__ idx,
+                                                    const double* __restrict__ in, double* __restrict__ out,
+                                                    const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
+    out[idx[i]] += in[i];
+}
+
 // sparse right-hand side -> dense (sleqp_vec_to_raw, sparse/vec.c:105-119); out pre-zeroed
 __global__ __launch_bounds__(FB) void k_scatter_sparse(int nnz, const int* __restrict__ idx,
                                                        const double* __restrict__ val, double* __restrict__ out) {
   for (int i = blockIdx.x * FB + threadIdx.x; i < nnz; i += gridDim.x * FB) out[idx[i]] = val[i];
-}
-
-// pivot statistics: min/max |d| over all fronts (condition estimate)
-__global__ __launch_bounds__(FB) void k_pivot_minmax(int ns, const SnDesc* __restrict__ sn,
-                                                     const double* __restrict__ L, double* __restrict__ out) {
-  __shared__ double smin[FB], smax[FB];
-  double lo = 1.7e308, hi = 0.0;
-  for (int s = blockIdx.x; s < ns; s += gridDim.x) {
-    const SnDesc S = sn[s];
-    for (int k = threadIdx.x; k < S.w; k += FB) {
-      const double d = fabs(L[S.Loff + k + (long long)k * S.r]);
-      lo = fmin(lo, d);
-      hi = fmax(hi, d);
-    }
-  }
-  smin[threadIdx.x] = lo;
-  smax[threadIdx.x] = hi;
-  __syncthreads();
-  for (int o = FB / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
-      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out[2 * blockIdx.x] = smin[0];
-    out[2 * blockIdx.x + 1] = smax[0];
-  }
 }
 
 // ---------------------------------------------------------------------------

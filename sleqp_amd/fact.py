@@ -106,6 +106,11 @@ class HipFact:
     def synchronize(self):
         self._check(self._lib.hipfact_synchronize(self._h))
 
+    def check(self):
+        """Blocks, finishes the refinement of the last solve and raises what the asynchronous
+        device-resident entry points could not report (singular, stalled, timed out)."""
+        self._check(self._lib.hipfact_check(self._h))
+
     def assemble_kkt(self, J: SleqpMat, var_index, cons_index, working_set_size: int, want_arrays: bool = True):
         """fill_aug_jac on the device (aug_jac/standard_aug_jac.c:135-237);
         returns the assembled lower CSC K (optional) and factors it."""

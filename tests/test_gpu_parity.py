@@ -71,37 +71,92 @@ def test_factor_solve_vs_oracle(fact, n, m, kind, frac, refine):
     assert rel_err(sv.to_raw(), oracle.vec_to_raw(N, oi, od)) <= REL_TOL
 
 
+def _judge(fact, N, kc, kr, kd, b, tag):
+    """One system against the LAPACK-restating oracle, no escape hatch: flat 1e-9 wherever the oracle
+    itself is that accurate (judged by an extended-precision reference); where partial-pivoting LU has
+    already lost more than that, the device must be at least as close to the reference as the oracle
+    (x4 slack) - or, like the oracle on exactly dependent rows, report the matrix as singular."""
+    from sleqp_amd import HipfactError
+    from sleqp_amd.sparse import SleqpMat
+    from util import reference_solution
+
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    try:
+        ref = oracle.OracleFact(N, kc, kr, kd)
+    except ZeroDivisionError:
+        with pytest.raises(HipfactError) as e:
+            fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            fact.solve(b)
+            fact.solution_raw(0, N)
+        assert e.value.code == -3, tag
+        return "singular"
+    ref.solve_dense(b)
+    zo = ref.raw_solution()
+    truth = reference_solution(K.toarray(), b, ref)
+    err_o = rel_err(zo, truth)
+    try:
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+    except HipfactError as e:
+        # only legitimate when the system is numerically singular: the oracle's own answer is then garbage
+        assert e.code == -3 and err_o > 1e-6, (tag, err_o, str(e))
+        return "singular"
+    err_d = rel_err(z, truth)
+    assert err_d <= max(REL_TOL, 4.0 * err_o), (tag, err_d, err_o)
+    if err_o <= 0.1 * REL_TOL:
+        assert rel_err(z, zo) <= REL_TOL, (tag, rel_err(z, zo))
+    assert scaled_residual(K, z, b) <= 1e-11, tag
+    return "ok"
+
+
 def test_random_sweep_vs_oracle(fact):
     """Seeded sweep over shapes, densities, active bounds and kernel configurations (per-level
     launches / single-launch top of the tree, pull / scatter extend-add): every solution against
-    the dense LAPACK-restating oracle."""
-    from sleqp_amd.sparse import SleqpMat
-
+    the dense LAPACK-restating oracle, including the ill-conditioned and singular draws."""
     rng = np.random.default_rng(2024)
+    outcomes = []
     for trial in range(24):
         n = int(rng.integers(20, 600))
         m = int(rng.integers(1, max(2, n // 2)))
         kind = "b" if trial % 2 else "u"
         frac = float(rng.choice([0.0, 0.05, 0.3]))
         J, vi, ci, W = _problem(n, m, kind, frac, 100 + trial)
-        if W > n:
-            continue
+        if W > n:  # more working-set rows than variables cannot have full row rank (pub_working_set.h:42-44)
+            ci = ci.copy()
+            ci[n - int((vi >= 0).sum()):] = -1
+            W = int((vi >= 0).sum() + (ci >= 0).sum())
         N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
-        K = synth.kkt_full_matrix(N, kc, kr, kd)
-        cond = np.linalg.cond(K.toarray())
-        if not np.isfinite(cond) or cond > 1e7:
-            continue  # (numerically) dependent working set: covered by test_error_behaviour
-        ref = oracle.OracleFact(N, kc, kr, kd)
         fact.set_option("factor_top_max", [100, 0, 6][trial % 3])
         fact.set_option("pull_max_children", [4, 0][(trial // 3) % 2])
-        fact.set_option("refine_steps", 1)
-        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
         b = rng.standard_normal(N)
-        ref.solve_dense(b)
-        fact.solve(b)
-        z = fact.solution_raw(0, N)
-        assert rel_err(z, ref.raw_solution()) <= 1e-9 * max(1.0, cond * 1e-3), (trial, n, m, kind, frac, cond)
-        assert scaled_residual(K, z, b) <= 1e-11, (trial, n, m, kind, frac)
+        outcomes.append(_judge(fact, N, kc, kr, kd, b, (trial, n, m, kind, frac)))
+    assert outcomes.count("ok") >= 16, outcomes
+
+
+def test_graded_conditioning_vs_oracle(fact):
+    """Row scalings 1e0..1e8, nearly parallel rows (1e-2..1e-5), column scalings and mixtures with
+    active bounds (what fact_ma57.c:444-507,743-763 handles by scaling + threshold
+    pivoting).  The constrained pivot order with exact row equilibration and refinement on K itself
+    stays within the flat tolerance of the oracle wherever the oracle is itself accurate, and beats
+    it elsewhere."""
+    from util import graded_family
+
+    seen = 0
+    for name, J, vi, ci in graded_family():
+        m, n = J.shape
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        b = np.random.default_rng(1).standard_normal(N)
+        assert _judge(fact, N, kc, kr, kd, b, name) == "ok", name
+        seen += 1
+        # the three AugJac right-hand-side shapes as well (standard_aug_jac.c:306-435)
+        g = np.zeros(N)
+        g[:n] = np.random.default_rng(2).standard_normal(n)
+        assert _judge(fact, N, kc, kr, kd, g, name + "/project") == "ok"
+        c = np.zeros(N)
+        c[n:] = np.random.default_rng(3).standard_normal(N - n)
+        assert _judge(fact, N, kc, kr, kd, c, name + "/min_norm") == "ok"
+    assert seen == 24
 
 
 def test_reference_known_answers_on_device(fact):
@@ -495,7 +550,8 @@ def test_non_finite_right_hand_side_does_not_stall_the_sweeps(fact):
     b = np.random.default_rng(6).standard_normal(N)
     fact.solve(b)
     good = fact.solution_raw(0, N)
-    for poison in (np.nan, np.inf, -np.inf):
+    sentinel_nan = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFFF).tobytes(), dtype=np.float64)[0]  # the slots' own bit pattern
+    for poison in (np.nan, np.inf, -np.inf, sentinel_nan):
         bad = b.copy()
         bad[N - 7] = poison   # a constraint row: enters the tree at a leaf and reaches the root
         bad[11] = poison
@@ -547,10 +603,10 @@ def test_full_size_properties(fact, workload):
     fact.solve(b)
     z = fact.solution_raw(0, N)
     assert scaled_residual(K, z, b) <= RESID_TOL
-    # (2) agreement with the oracle's sparse LDL^T (CPU baseline, BASELINE.md: <= 1e-8)
-    if workload.startswith("banded"):
-        x = oracle.OracleLdl(N, cp, ri, vx).solve(b)
-        assert rel_err(z, x) <= 1e-8
+    # (2) agreement with the oracle's sparse LDL^T (CPU baseline, BASELINE.md: <= 1e-8); for the
+    # dense-Schur family this is a 5000^2 dense factorisation inside the simplicial code (~15 s)
+    x = oracle.OracleLdl(N, cp, ri, vx).solve(b)
+    assert rel_err(z, x) <= 1e-8
     # (3) linearity
     b2 = np.random.default_rng(9).standard_normal(N)
     fact.solve(b2)
@@ -596,21 +652,25 @@ def test_adaptive_refinement_and_graphs(fact):
     assert np.array_equal(outs[0], outs[1])
     assert fact.info("num_graphs") == 0
     fact.set_option("use_graph", 1)
-    # a tolerance nobody can meet forces the correction pass; a loose one suppresses it
+    # well conditioned: the first pass meets the tolerance, the correction pass of the graph is skipped
     n0 = fact.info("num_refined")
-    fact.set_option("refine_tol", 0.0)
     fact.solve(b)
-    assert fact.info("num_refined") == n0 + 1
-    z_ref = fact.solution_raw(0, N)
-    fact.set_option("refine_tol", 1.0)
+    z_one = fact.solution_raw(0, N)
+    assert fact.info("num_refined") == n0 and fact.info("last_iters") == 0 and fact.info("last_status") == 0
+    assert fact.info("last_omega") <= 1e-14
+    # non-adaptive: exactly refine_steps passes, whatever the residual says
+    fact.set_option("refine_adaptive", 0)
+    fact.set_option("refine_steps", 2)
     fact.solve(b)
+    assert rel_err(fact.solution_raw(0, N), z_one) <= 1e-12 and fact.info("last_iters") == 2
     assert fact.info("num_refined") == n0 + 1
-    assert rel_err(fact.solution_raw(0, N), z_ref) <= 1e-10
-    # badly scaled rows: the plain solve loses accuracy, the residual check brings it back
+    fact.set_option("refine_adaptive", 1)
+    fact.set_option("refine_steps", 1)
+    # badly scaled rows: exact row equilibration makes them harmless
     Jb = sp.csc_matrix(sp.diags(np.logspace(0, 5, 400)) @ J)
     N2, c2, r2, d2 = oracle.fill_aug_jac(800, 400, Jb.indptr, Jb.indices, Jb.data, vi, ci)
     K2 = synth.kkt_full_matrix(N2, c2, r2, d2)
-    fact.set_option("refine_tol", 5e-13)
+    fact.set_option("refine_tol", 1e-10)
     fact.set_matrix(SleqpMat(N2, N2, c2, r2, d2))
     fact.solve(b)
     assert scaled_residual(K2, fact.solution_raw(0, N2), b) <= RESID_TOL
