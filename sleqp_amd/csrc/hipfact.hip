@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,23 @@ namespace hipfact {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
   ~DevBuf() { release(); }
   void release() {
     if (p) (void)hipFree(p);
@@ -105,57 +124,119 @@ using namespace hipfact;
 
 static thread_local std::string g_create_error;
 
-struct hipfact_handle {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string error;
-  PlanParams prm;
+struct GraphEntry {
+  int kind;  // 0 factor, 1 solve (first pass, residual, in-graph correction passes), 2 continuation passes
+  const void* b;
+  void* z;
+  int passes;  // correction passes inside the graph
+  hipGraphExec_t exec;
+};
+
+// Everything that belongs to ONE symbolic plan: the plan, its device image, the numeric arenas
+// and the captured graphs (which hold pointers into exactly these buffers).  The handle IS the
+// active state (it derives from this struct, so h->d_L etc. address the active plan); states of
+// other sparsity patterns / working-set supersets wait in an LRU list and are swapped in whole,
+// so coming back to a pattern seen before costs neither an analysis nor an upload nor a capture.
+struct PlanState {
   Plan plan;
   bool have_plan = false, factored = false, solved = false;
-  bool prod_packed = false;  // product lists as one packed word per pair
-  bool idx32 = false;  // product-list pointers and panel targets fit 32 bits
-  int refine_steps = 1;
-  bool refine_adaptive = true;   // run the correction pass only when the residual asks for it
-  double refine_tol = 5e-13;     // on ||b - K z||_inf / ||b||_inf
-  long num_refined = 0;          // solves that needed a correction pass
-  bool use_graph = true;         // replay captured hipGraphs instead of re-enqueueing ~100 launches
-  struct GraphEntry {
-    int kind;  // 0 factor, 1 solve first pass (+ residual, norms), 2 correction pass
-    const void* b;
-    void* z;
-    int refine_steps;
-    bool adaptive;
-    hipGraphExec_t exec;
-  };
+  bool factor_checked = false;  // info words of the last factorisation have been read back
+  bool prod_packed = false;     // product lists as one packed word per pair
+  bool idx32 = false;           // product-list pointers and panel targets fit 32 bits
+  unsigned long long key_hash = 0;  // FNV-1a of the pattern the plan was built for
+  // superset plans (hipfact_assemble_kkt): pattern of J and the constraint rows the structure covers
+  bool from_jacobian = false;
+  std::vector<int> Jp, Ji;    // cons_jac pattern (CSC) the plan was built for
+  std::vector<int> sidx;      // per constraint row of J: its row in the structure, -1 = not covered
+  int m_struct = 0;           // rows covered
+  bool maps_on = false;       // d_vmap / d_cmap translate between the caller's numbering and the structure
+  int N_ext = 0;              // dimension of the caller's vectors (n + |W|); == plan.N without maps
+  int n_bounds = 0;           // active bounds of the current working set
+  unsigned long long use_stamp = 0;  // LRU clock
+  int refine_inline = 1;      // correction passes currently carried by the solve graphs
+  int seq_at_factor = 0;      // handle's solve_seq at the time of the last factorisation
+  bool inline_probe = true;   // the first solve of this factorisation has not been looked at yet
   std::vector<GraphEntry> graphs;
-  int debug_phases = 15;
-  int split_max_fronts = 1 << 30;
-  int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
-  int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
-  int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
-  int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
-  int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
-  int pull_max_children = 4;  // 0: always the separate assembly kernel; otherwise pull for any number of children
-  double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family  // levels with at most this many fronts use the split kernels  // timing-only phase mask of k_factor_level (15 = everything)
-  long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
-  int info_host[INFO_WORDS] = {0, 0, 0, 0};
+  double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family
   std::vector<LevelInfo> levels;
   // top of the tree solved in one launch per direction (levels >= top_level)
-  int top_level = 1 << 30, top_count = 0, top_max_fronts = 1024;
+  int top_level = 1 << 30, top_count = 0;
   size_t top_lds_fwd = 0, top_lds_bwd = 0;
-  Prof prof;
   // plan on device
   DevBuf d_sn, d_level_sn, d_rows, d_rel, d_child, d_Mtarget, d_prod_ptr, d_prod_a, d_prod_b, d_src;
   DevBuf d_items, d_fitems, d_top_sn, d_titems, d_flags, d_inv, d_tfitems, d_ftarget, d_wpart, d_pullx;
   DevBuf d_perm, d_Ar_ptr, d_Ar_col, d_Ar_src, d_Ar_val, d_Kp, d_Ki, d_Kc_y, d_Tp, d_Ti, d_Tsrc;
   // numeric
   DevBuf d_xarena;  // posted pivot blocks of the single-launch factorisation (polled by its panel workgroups)
-  DevBuf d_ysol;  // polled copy of the solution of M y = t (single-launch backward sweep)
-  DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res, d_corr, d_info, d_minmax, d_sp_idx, d_sp_val, d_norms;
-  PinBuf h_norms;
+  DevBuf d_ysol;    // polled copy of the solution of M y = t (single-launch backward sweep)
+  DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res;
+  DevBuf d_Ksc, d_Kprod, d_dscale, d_vmap, d_cmap, d_diag_target, d_sidx;
+
+  PlanState() = default;
+  PlanState(PlanState&&) = default;
+  PlanState& operator=(PlanState&& o) {
+    if (this != &o) {
+      destroy_graphs();
+      this->~PlanState();
+      new (this) PlanState(std::move(o));
+    }
+    return *this;
+  }
+  void destroy_graphs() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+    graphs.clear();
+  }
+  ~PlanState() { destroy_graphs(); }
+};
+
+struct hipfact_handle : PlanState {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  PlanParams prm;
+  std::vector<std::unique_ptr<PlanState>> cache;  // inactive plan states, at most plan_cache_max
+  int plan_cache_max = 4;
+  unsigned long long use_clock = 0;
+  long plan_swaps = 0;
+  // Iterative refinement on K itself, controlled on the device (RefineCtl): every solve graph holds
+  // the first pass, the residual, and `refine_inline` correction passes whose kernels return at once
+  // when the control block says "done".  Entry points that synchronise anyway (hipfact_solution,
+  // hipfact_check, the dot products of the projected CG) continue a solve that is still not done,
+  // up to `refine_max` passes in total, and remember how many it took for the next solves.
+  int refine_steps = 1;          // correction passes inside the solve graph (0: no residual at all)
+  int refine_max = 10;           // total passes including the host-continued ones
+  bool refine_adaptive = true;   // false: every in-graph pass runs unconditionally
+  double refine_tol = 1e-10;     // forward-error target: backward-error tolerance = refine_tol / kappa_est
+  double fail_omega = 1e-8;      // a solve that stalls above this backward error is reported as singular
+  bool equilibrate = true;       // row equilibration of the constraint block (saddle mode)
+  long num_refined = 0;          // solves that applied at least one correction pass
+  long num_passes = 0;           // correction passes applied in total
+  bool ctl_pending = false;      // the control block of the last solve has not been looked at yet
+  const double* last_b = nullptr;
+  double* last_z = nullptr;
+  RefineCtl last_ctl = {1, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+  int solve_seq = 0;             // solves with a residual queued since the control block was last cleared
+  bool use_graph = true;         // replay captured hipGraphs instead of re-enqueueing ~100 launches
+  int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
+  int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
+  int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
+  int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
+  int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
+  int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
+  int pull_max_children = 4;  // 0: always the separate assembly kernel; otherwise pull for any number of children
+  int top_max_fronts = 1024;
+  long cache_hits = 0, analyses = 0, num_factor = 0, num_solve = 0;
+  int info_host[INFO_WORDS] = {0, 0, 0, 0};
+  Prof prof;
+  // shared by all plan states (fixed size, never reallocated: graphs of every state may point at them)
+  DevBuf d_info, d_norms, d_ctl;
+  PinBuf h_ctl;
+  void* h_ctl_dev = nullptr;  // device address of the pinned copy of the control block
   PinBuf h_stage, h_info;
+  DevBuf d_sp_idx, d_sp_val;
   // assembly
   DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
   // projected CG
@@ -714,7 +795,7 @@ static int upload_plan(hipfact_handle* h) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // numeric workspaces
   HCHECK(h, h->d_Kval.ensure(std::max<size_t>((size_t)P.nnzK * sizeof(double), 16)));
-  HCHECK(h, h->d_L.ensure((size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int) + 16));
+  HCHECK(h, h->d_L.ensure((size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int) + 32));
   HCHECK(h, h->d_U.ensure(std::max<size_t>((size_t)P.U_size * sizeof(double), 16)));
   HCHECK(h, h->d_uvec.ensure(std::max<size_t>((size_t)P.u_size * sizeof(double), 16)));
   HCHECK(h, h->d_y.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
@@ -727,37 +808,66 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_rhs.ensure(nb));
   HCHECK(h, h->d_sol.ensure(nb));
   HCHECK(h, h->d_res.ensure(nb));
-  HCHECK(h, h->d_corr.ensure(nb));
-  HCHECK(h, h->d_info.ensure(INFO_WORDS * sizeof(int)));
-  HCHECK(h, h->d_minmax.ensure(2 * 64 * sizeof(double)));
-  HCHECK(h, h->d_norms.ensure(2 * sizeof(double) * 4096));
-  HCHECK(h, h->h_norms.ensure(2 * sizeof(double) * 4096));
+  HCHECK(h, h->d_info.ensure(INFO_BYTES));  // info words + pivot min / max
+  HCHECK(h, h->d_norms.ensure(3 * sizeof(double) * 4096));
   HCHECK(h, h->h_info.ensure(INFO_WORDS * sizeof(int) + 2 * 64 * sizeof(double)));
+  if (!h->d_ctl.p) {
+    HCHECK(h, h->d_ctl.ensure(sizeof(RefineCtl)));
+    HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), h->stream));
+  }
+  if (!h->h_ctl.p) {
+    HCHECK(h, h->h_ctl.ensure(sizeof(RefineCtl)));
+    memset(h->h_ctl.p, 0, sizeof(RefineCtl));
+    HCHECK(h, hipHostGetDevicePointer(&h->h_ctl_dev, h->h_ctl.p, 0));
+  }
+  if (P.saddle) {
+    HCHECK(h, h->d_Ksc.ensure(std::max<size_t>((size_t)P.nnzK * sizeof(double), 16)));
+    HCHECK(h, h->d_dscale.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+  }
   return HIPFACT_OK;
+}
+
+static inline unsigned long long* minmax_ptr(const hipfact_handle* h) {
+  return reinterpret_cast<unsigned long long*>(h->d_info.as<char>() + INFO_WORDS * sizeof(int));
 }
 
 // queue the numeric factorisation on the stream (values already in d_Kval)
 static int factor_enqueue(hipfact_handle* h) {
   const Plan& P = h->plan;
   hipStream_t st = h->stream;
-  HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_WORDS * sizeof(int), st));
-  if (P.L_size > 0) {
-    prof_begin(h, PC_MEMSET);
-    // the dependency counters of k_factor_top live behind the arena: one fill clears both
-    HCHECK(h, hipMemsetAsync(h->d_L.p, 0, (size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int), st));
-    prof_end(h);
+  // the dependency counters of k_factor_top live behind the arena: one fill clears both
+  const size_t fill_bytes = (size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int);
+  const bool fill_rides = P.saddle && P.n > 0 && P.m > 0;  // inside k_row_scale (with the info words)
+  if (!fill_rides) {
+    HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
+    if (P.L_size > 0) {
+      prof_begin(h, PC_MEMSET);
+      HCHECK(h, hipMemsetAsync(h->d_L.p, 0, fill_bytes, st));
+      prof_end(h);
+    }
   }
   const long long nM = (long long)P.Mi.size();
-  bool gathered = false;
+  const int* vmap = h->maps_on ? h->d_vmap.as<int>() : nullptr;
+  double* kprod = h->maps_on ? h->d_Kprod.as<double>() : h->d_Ksc.as<double>();
+  if (P.saddle && P.n > 0) {
+    // row equilibration (exact powers of two), A^ in pivot order for the solves' SpMVs, scaled
+    // copy of K's values for the Schur-complement products and the x update
+    if (P.m > 0) {
+      const long long nz16 = (long long)((fill_bytes + 15) / 16);
+      const int nbz = (int)std::min<long long>(2048, std::max<long long>(1, nz16 / (FB * 8)));
+      LAUNCH(PC_GATHER, k_row_scale, dim3(nbz + nblocks((long long)P.m * 16)), dim3(FB), 0, P.m,
+             h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_src.as<int>(), h->d_Kval.as<double>(), vmap,
+             h->equilibrate ? 1 : 0, h->d_dscale.as<double>(), h->d_Ar_val.as<double>(), h->d_Ksc.as<double>(), kprod,
+             nbz, h->d_L.as<double2>(), nz16, h->d_info.as<int>());
+    }
+  }
   if (nM > 0) {
     if (P.saddle) {
-      // the gather of A's values for the solves rides along in the same launch
-      const long long na = (long long)P.Ar_src.size();
-      const int nbg = na > 0 ? nblocks(na, 1 << 12) : 0;
-      gathered = na > 0;
+      const long long na = 0;
+      const int nbg = 0;
 #define MVALS_LAUNCH(IDX, PK)                                                                                       \
   LAUNCH(PC_MVALS, (k_mvals_prod<IDX, PK>), dim3(nblocks(nM, 1 << 16) + nbg), dim3(FB), 0, nM, h->d_prod_ptr.as<IDX>(), \
-         h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), h->d_Mtarget.as<IDX>(), h->d_Kval.as<double>(),                 \
+         h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), h->d_Mtarget.as<IDX>(), kprod,                                  \
          h->d_L.as<double>(), na, nbg, h->d_Ar_src.as<int>(), h->d_Ar_val.as<double>())
       if (h->idx32 && h->prod_packed)
         MVALS_LAUNCH(unsigned int, true);
@@ -773,11 +883,9 @@ static int factor_enqueue(hipfact_handle* h) {
                          h->d_Mtarget.as<long long>(), h->d_Kval.as<double>(), h->d_L.as<double>());
     }
   }
-  if (P.saddle && !P.Ar_src.empty() && !gathered) {
-    const long long na = (long long)P.Ar_src.size();
-    LAUNCH(PC_GATHER, k_gather, dim3(nblocks(na, 1 << 16)), dim3(FB), 0, na, h->d_Ar_src.as<int>(),
-                       h->d_Kval.as<double>(), h->d_Ar_val.as<double>());
-  }
+  if (P.saddle && h->maps_on && P.m > 0)
+    LAUNCH(PC_GATHER, k_diag_inactive, dim3(nblocks(P.m)), dim3(FB), 0, P.m, h->d_perm.as<int>(), h->d_cmap.as<int>(),
+           h->d_diag_target.as<long long>(), h->d_L.as<double>());
   const int lsplit = h->debug_phases == 15 ? std::min(h->ftop_level, P.nlevels) : P.nlevels;
   for (int l = 0; l < lsplit; ++l) {
     const LevelInfo& li = h->levels[l];
@@ -822,39 +930,93 @@ static int factor_enqueue(hipfact_handle* h) {
 }
 
 template <class F>
-static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue);
+static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue, int passes = 0);
 
 static int factor_async(hipfact_handle* h) {
   const int rc = run_cached(h, 0, nullptr, nullptr, [&] { return factor_enqueue(h); });
   if (rc) return rc;
   h->num_factor++;
   h->factored = true;
+  h->factor_checked = false;
   h->solved = false;
+  h->ctl_pending = false;
+  h->refine_inline = h->refine_steps;
+  h->inline_probe = true;
+  h->seq_at_factor = h->solve_seq;
   return HIPFACT_OK;
 }
 
-static int check_info(hipfact_handle* h) {
+// The dataflow launches exchange data through sentinel-initialised slots and counters; after a
+// timed-out launch that state is undefined.  Put all of it back (fresh launches, same process).
+static int reset_dataflow_state(hipfact_handle* h) {
+  const Plan& P = h->plan;
+  hipStream_t st = h->stream;
+  if (h->d_xarena.p) HCHECK(h, hipMemsetAsync(h->d_xarena.p, 0xFF, h->d_xarena.bytes, st));
+  if (h->d_uvec.p) HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), st));
+  if (h->d_ysol.p) HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), st));
+  if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
+  HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
+  HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));
+  HCHECK(h, hipStreamSynchronize(st));
+  memset(h->h_ctl.p, 0, sizeof(RefineCtl));
+  h->solve_seq = h->seq_at_factor = 0;
+  h->ctl_pending = false;
+  return HIPFACT_OK;
+}
+
+// Reads back the info words of the last factorisation (blocking).  Zero / non-finite pivots, a
+// negative pivot of the Schur complement A A^T (saddle mode: it is SPD unless the working set is
+// rank deficient) and dependency-wait timeouts all invalidate the factorisation.
+static int check_info(hipfact_handle* h, const char* phase = "factorisation") {
   HCHECK(h, hipMemcpyAsync(h->h_info.p, h->d_info.p, INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   memcpy(h->info_host, h->h_info.p, INFO_WORDS * sizeof(int));
+  h->factor_checked = true;
+  char buf[200];
+  if (h->info_host[INFO_TIMEOUT] != 0) {
+    snprintf(buf, sizeof buf, "dependency wait timed out inside the single-launch %s kernels (%d waits)", phase,
+             h->info_host[INFO_TIMEOUT]);
+    h->factored = false;
+    h->solved = false;
+    const int rc = reset_dataflow_state(h);
+    h->error = buf;
+    return rc ? rc : HIPFACT_EINTERNAL;
+  }
   if (h->info_host[INFO_ZERO_PIVOT] > 0) {
-    char buf[160];
     snprintf(buf, sizeof buf, "matrix is singular: %d zero or non-finite pivot(s)", h->info_host[INFO_ZERO_PIVOT]);
     h->error = buf;
+    h->factored = false;
+    return HIPFACT_ESINGULAR;
+  }
+  if (h->plan.saddle && h->info_host[INFO_NEG_PIVOT] > 0) {
+    snprintf(buf, sizeof buf, "working set is numerically rank deficient: %d negative pivot(s) of A A^T",
+             h->info_host[INFO_NEG_PIVOT]);
+    h->error = buf;
+    h->factored = false;
     return HIPFACT_ESINGULAR;
   }
   return HIPFACT_OK;
 }
 
-// M y = t on the device (y in: t in pivot order, out: solution)
-static void solve_m_async(hipfact_handle* h) {
+static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
+  SaddleMaps M;
+  M.vmap = h->maps_on ? h->d_vmap.as<int>() : nullptr;
+  M.cmap = h->maps_on ? h->d_cmap.as<int>() : nullptr;
+  M.dscale = h->d_dscale.as<double>();
+  M.n = h->plan.n;
+  return M;
+}
+
+// M y = t on the device (y in: t in pivot order, out: solution); skip: device flag that turns
+// every launch into a no-op (correction passes of a solve that has already converged)
+static void solve_m_async(hipfact_handle* h, const int* skip) {
   const Plan& P = h->plan;
   const int ltop = std::min(h->top_level, P.nlevels);
   for (int l = 0; l < ltop; ++l) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(SB), li.lds_fwd, h->d_sn.as<SnDesc>(),
            h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
-           h->d_y.as<double>(), h->d_uvec.as<double>());
+           h->d_y.as<double>(), h->d_uvec.as<double>(), skip);
   }
   if (ltop < P.nlevels) {
     // two flag sets, one per sweep; each kernel clears the other one's (zero after upload_plan)
@@ -863,72 +1025,81 @@ static void solve_m_async(hipfact_handle* h) {
     LAUNCH(PC_FWD, k_fwd_top, dim3(h->top_count), dim3(SB), h->top_lds_fwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), ltop, h->d_L.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>(),
            h->d_inv.as<int>(), h->d_ftarget.as<int>(), h->d_y.as<double>(), h->d_uvec.as<double>(),
-           ffl, ffl + P.nsuper, h->d_info.as<int>(), bfl, 2 * P.nsuper, h->d_ysol.as<double>());
+           ffl, ffl + P.nsuper, h->d_info.as<int>(), bfl, 2 * P.nsuper, h->d_ysol.as<double>(), skip);
     LAUNCH(PC_BWD, k_bwd_top, dim3(h->top_count), dim3(SB), h->top_lds_bwd, h->d_sn.as<SnDesc>(),
            h->d_titems.as<TopItem>(), h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_wpart.as<double>(), bfl, bfl + P.nsuper, h->d_info.as<int>(), ffl, 2 * P.nsuper,
-           h->d_ysol.as<double>(), h->d_uvec.as<double>());
+           h->d_ysol.as<double>(), h->d_uvec.as<double>(), skip);
   }
   for (int l = ltop - 1; l >= 0; --l) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_BWD, k_bwd_level, dim3(li.count), dim3(SB), li.lds_bwd, h->d_sn.as<SnDesc>(),
-           h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>());
+           h->d_level_sn.as<int>() + li.begin, h->d_L.as<double>(), h->d_rows.as<int>(), h->d_y.as<double>(), skip);
   }
 }
 
-// z = K^-1 b without refinement; b, z device vectors of length N (may alias)
-static void solve_once_async(hipfact_handle* h, const double* b, double* z) {
+// z = K^-1 b (acc: z += K^-1 b) without refinement; b, z device vectors in the caller's
+// numbering, b != z
+static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool acc, const int* skip) {
   const Plan& P = h->plan;
   if (P.N == 0) return;
   if (P.saddle) {
+    const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
-      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks((long long)P.m * 16)), dim3(FB), 0, P.m, P.n, h->d_Ar_ptr.as<int>(),
-                         h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b,
-                         h->d_y.as<double>());
-      solve_m_async(h);
+      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks((long long)P.m * 16)), dim3(FB), 0, P.m, h->d_Ar_ptr.as<int>(),
+             h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b, h->d_y.as<double>(), skip);
+      solve_m_async(h, skip);
     }
-    LAUNCH(PC_XUPD, k_x_saddle, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
-                       h->d_Kval.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), h->d_y.as<double>(), b, z);
+    if (acc)
+      LAUNCH(PC_XUPD, k_x_saddle<true>, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
+             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip);
+    else
+      LAUNCH(PC_XUPD, k_x_saddle<false>, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
+             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip);
   } else {
-    LAUNCH(PC_PERM, k_gather, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(), b,
-                       h->d_y.as<double>());
-    solve_m_async(h);
-    LAUNCH(PC_PERM, k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
-                       h->d_y.as<double>(), z);
+    LAUNCH(PC_PERM, k_gather_skip, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(), b,
+           h->d_y.as<double>(), skip);
+    solve_m_async(h, skip);
+    if (acc)
+      LAUNCH(PC_PERM, k_scatter_acc, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
+             h->d_y.as<double>(), z, skip);
+    else
+      LAUNCH(PC_PERM, k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
+             h->d_y.as<double>(), z);
   }
 }
 
-// grid of the residual kernels (= number of max-norm partial pairs they write)
-static inline int resid_blocks(const Plan& P) { return P.saddle ? nblocks((long long)P.N * 8, 2048) : nblocks(P.N); }
+// grid of the residual kernels (= number of partial maxima they leave)
+static inline int resid_blocks(const Plan& P) { return P.saddle ? nblocks((long long)P.N * 8, 2048) : nblocks(P.N, 2048); }
 
-static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool norms = false) {
-  double* nptr = norms ? h->d_norms.as<double>() : nullptr;
+// res = b - K z; updates the refinement control block (first: the residual of the first pass)
+static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool first) {
   const Plan& P = h->plan;
+  RefineCtl* ctl = h->d_ctl.as<RefineCtl>();
+  // non-adaptive mode (negative target): every in-graph pass runs
+  const double target = h->refine_adaptive ? h->refine_tol : -1.0;
   if (P.saddle) {
     LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
-                       h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
-                       h->d_Ar_val.as<double>(), h->d_perm.as<int>(), b, z, res, nptr);
+           h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
+           h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl,
+           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), first ? 1 : 0, target, minmax_ptr(h));
   } else {
-    LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(),
-                       h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(),
-                       h->d_Tsrc.as<int>(), b, z, res, nptr);
+    LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(), h->d_Ki.as<int>(),
+           h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(), h->d_Tsrc.as<int>(), b, z, res, ctl,
+           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), first ? 1 : 0, target, minmax_ptr(h));
   }
 }
 
-static void drop_graphs(hipfact_handle* h) {
-  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-  h->graphs.clear();
-}
+static void drop_graphs(hipfact_handle* h) { h->destroy_graphs(); }
 
 // Runs `enqueue` (a function that only queues work on h->stream) through a
 // cached hipGraph; falls back to direct enqueueing when graphs are disabled,
 // while profiling with events, or when capture is not possible.
 template <class F>
-static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue) {
+static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue, int passes) {
   if (!h->use_graph || h->prof.on || h->debug_phases != 15) return enqueue();
   for (auto& g : h->graphs)
-    if (g.kind == kind && g.b == b && g.z == z && g.refine_steps == h->refine_steps &&
-        g.adaptive == h->refine_adaptive) {
+    if (g.kind == kind && g.b == b && g.z == z && g.passes == passes) {
       HCHECK(h, hipGraphLaunch(g.exec, h->stream));
       return HIPFACT_OK;
     }
@@ -955,70 +1126,102 @@ static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enq
     return enqueue();
   }
   if (h->graphs.size() >= 16) drop_graphs(h);
-  h->graphs.push_back({kind, b, z, h->refine_steps, h->refine_adaptive, exec});
+  h->graphs.push_back({kind, b, z, passes, exec});
   HCHECK(h, hipGraphLaunch(exec, h->stream));
   return HIPFACT_OK;
 }
 
-// first pass: z = K^-1 b, then (when refinement is enabled) res = b - K z and its norms
-static int solve_first_enqueue(hipfact_handle* h, const double* b, double* z) {
+// `passes` correction passes z += K^-1 res, res and the control block recomputed after each; every
+// kernel returns at once when the control block says "done"
+static int correct_enqueue(hipfact_handle* h, const double* bb, double* z, int passes) {
+  const int* skip = &h->d_ctl.as<RefineCtl>()->done;
+  for (int it = 0; it < passes; ++it) {
+    solve_once_async(h, h->d_res.as<double>(), z, true, skip);
+    residual_async(h, bb, z, h->d_res.as<double>(), false);
+  }
+  HCHECK(h, hipGetLastError());
+  return HIPFACT_OK;
+}
+
+// first pass z = K^-1 b, residual, and the in-graph correction passes
+static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
   const double* bb = b;
   if (h->refine_steps > 0 && b == z) {  // keep a private copy of b for the residual
     HCHECK(h, hipMemcpyAsync(h->d_rhs.p, b, (size_t)P.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     bb = h->d_rhs.as<double>();
   }
-  solve_once_async(h, bb, z);
+  solve_once_async(h, bb, z, false, nullptr);
   if (h->refine_steps > 0) {
-    residual_async(h, bb, z, h->d_res.as<double>(), h->refine_adaptive);
-    if (h->refine_adaptive)
-      HCHECK(h, hipMemcpyAsync(h->h_norms.p, h->d_norms.p, 2 * sizeof(double) * resid_blocks(P), hipMemcpyDeviceToHost,
-                               h->stream));
+    residual_async(h, bb, z, h->d_res.as<double>(), true);
+    return correct_enqueue(h, bb, z, h->refine_inline);
   }
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;
 }
 
-// correction passes: z += K^-1 res, res recomputed between passes
-static int solve_correct_enqueue(hipfact_handle* h, const double* b, double* z, int passes) {
-  const Plan& P = h->plan;
-  const double* bb = (b == z) ? h->d_rhs.as<double>() : b;
-  for (int it = 0; it < passes; ++it) {
-    if (it > 0) residual_async(h, bb, z, h->d_res.as<double>());
-    solve_once_async(h, h->d_res.as<double>(), h->d_corr.as<double>());
-    LAUNCH(PC_AXPY, k_axpy, dim3(nblocks(P.N)), dim3(FB), 0, (long long)P.N, 1.0, h->d_corr.as<double>(), z);
-  }
-  HCHECK(h, hipGetLastError());
-  return HIPFACT_OK;
-}
-
-// full solve with iterative refinement on K itself: fixed number of correction
-// passes, or (default) one pass only when the relative residual exceeds refine_tol
+// Queues a full solve.  No host synchronisation: the refinement loop is controlled on the device.
 static int solve_async(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
   if (P.N == 0) return HIPFACT_OK;
-  int rc = run_cached(h, 1, b, z, [&] { return solve_first_enqueue(h, b, z); });
-  if (rc) return rc;
-  if (h->refine_steps > 0) {
-    bool correct = true;
-    if (h->refine_adaptive) {
-      HCHECK(h, hipStreamSynchronize(h->stream));
-      double rn = 0.0, bn = 0.0;
-      const double* part = h->h_norms.as<double>();
-      for (int q = 0, nq = resid_blocks(P); q < nq; ++q) {
-        rn = (part[2 * q] > rn || part[2 * q] != part[2 * q]) ? part[2 * q] : rn;
-        bn = std::max(bn, part[2 * q + 1]);
-      }
-      correct = !(rn <= h->refine_tol * bn);  // also true for NaN
-    }
-    if (correct) {
-      h->num_refined++;
-      rc = run_cached(h, 2, b, z, [&] { return solve_correct_enqueue(h, b, z, h->refine_steps); });
-      if (rc) return rc;
+  if (h->refine_steps > 0 && h->refine_adaptive && h->inline_probe && h->solve_seq > h->seq_at_factor) {
+    // Has the previous solve of this factorisation been judged yet?  (A peek at the pinned copy, no
+    // synchronisation.)  If its first pass met the tolerance with room to spare, the following
+    // solves drop the correction pass from their graph - its kernels would return at once, but 883
+    // workgroups per launch still have to be dispatched for that.  A solve that does need a pass is
+    // continued at the next synchronising entry point, which also puts the pass back.
+    const RefineCtl* hc = h->h_ctl.as<RefineCtl>();
+    if (__atomic_load_n(&hc->seq, __ATOMIC_ACQUIRE) == h->solve_seq) {
+      if (hc->done && hc->status == 0 && hc->iters == 0 && hc->omega <= 0.25 * hc->tol) h->refine_inline = 0;
+      h->inline_probe = false;
     }
   }
+  int rc = run_cached(h, 1, b, z, [&] { return solve_enqueue(h, b, z); }, h->refine_steps > 0 ? h->refine_inline : -1);
+  if (rc) return rc;
   h->num_solve++;
   h->solved = true;
+  if (h->refine_steps > 0) h->solve_seq++;
+  h->ctl_pending = h->refine_steps > 0;
+  h->last_b = (b == z) ? h->d_rhs.as<double>() : b;
+  h->last_z = z;
+  return HIPFACT_OK;
+}
+
+// Called by entry points that synchronise anyway: looks at the control block of the last solve,
+// continues a refinement that is still running, and reports a solve that stalled far above the
+// tolerance (numerically singular working set) or a timed-out dataflow launch.
+static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
+  if (continued) *continued = false;
+  if (!h->ctl_pending) return HIPFACT_OK;
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  RefineCtl c;
+  memcpy(&c, h->h_ctl.p, sizeof(c));
+  int more = 0;
+  while (!c.done && h->refine_adaptive && c.iters < h->refine_max) {
+    const int passes = std::min(std::max(h->refine_inline, 1), h->refine_max - c.iters);
+    const double* b = h->last_b;
+    double* z = h->last_z;
+    int rc = run_cached(h, 2, b, z, [&] { return correct_enqueue(h, b, z, passes); }, passes);
+    if (rc) return rc;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    memcpy(&c, h->h_ctl.p, sizeof(c));
+    ++more;
+  }
+  h->ctl_pending = false;
+  h->last_ctl = c;
+  if (continued) *continued = more > 0;
+  if (c.iters > 0) h->num_refined++;
+  h->num_passes += c.iters;
+  // the next solves of this factorisation carry as many passes in their graph as this one needed
+  if (more > 0) h->refine_inline = std::min(std::max(h->refine_inline, c.iters), 4);
+  if (h->refine_adaptive && c.status != 2 && c.omega > h->fail_omega) {
+    char buf[200];
+    snprintf(buf, sizeof buf,
+             "working set is numerically singular: iterative refinement stalled at backward error %.2e after %d "
+             "passes (pivot-ratio condition estimate %.2e)", c.omega, c.iters, c.kappa);
+    h->error = buf;
+    return HIPFACT_ESINGULAR;
+  }
   return HIPFACT_OK;
 }
 
@@ -1147,6 +1350,7 @@ int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* r
   if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) return rc;
   const size_t nnz = (size_t)h->plan.nnzK;
   if (nnz > 0) {
+    HCHECK(h, hipStreamSynchronize(h->stream));  // a copy out of the staging buffer may still be in flight
     HCHECK(h, h->h_stage.ensure(nnz * sizeof(double)));
     memcpy(h->h_stage.p, vals, nnz * sizeof(double));
     HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->h_stage.p, nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1183,8 +1387,8 @@ int hipfact_solve_dense(hipfact_handle* h, const double* rhs) {
   const size_t N = (size_t)h->plan.N;
   if (N == 0) return HIPFACT_OK;
   if (!rhs) return HIPFACT_EINVAL;
-  HCHECK(h, h->h_stage.ensure(N * sizeof(double)));
   HCHECK(h, hipStreamSynchronize(h->stream));  // staging buffer may still be in flight
+  HCHECK(h, h->h_stage.ensure(N * sizeof(double)));
   memcpy(h->h_stage.p, rhs, N * sizeof(double));
   HCHECK(h, hipMemcpyAsync(h->d_rhs.p, h->h_stage.p, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   return solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
@@ -1208,10 +1412,10 @@ int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices
   HCHECK(h, hipMemsetAsync(h->d_rhs.p, 0, (size_t)N * sizeof(double), h->stream));
   if (nnz > 0) {
     const size_t bytes = (size_t)nnz * (sizeof(double) + sizeof(int));
+    HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, h->h_stage.ensure(bytes));
     HCHECK(h, h->d_sp_val.ensure((size_t)nnz * sizeof(double)));
     HCHECK(h, h->d_sp_idx.ensure((size_t)nnz * sizeof(int)));
-    HCHECK(h, hipStreamSynchronize(h->stream));
     double* sv = h->h_stage.as<double>();
     int* si = reinterpret_cast<int*>(sv + nnz);
     memcpy(sv, data, (size_t)nnz * sizeof(double));
@@ -1244,18 +1448,24 @@ int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
     return HIPFACT_EINVAL;
   }
   const size_t cnt = (size_t)(end - begin);
+  // the refinement of the last solve is finished (and a stalled one reported) before its result leaves
+  if ((rc = finish_solve(h))) return rc;
   if (cnt == 0) return HIPFACT_OK;
+  HCHECK(h, hipStreamSynchronize(h->stream));
   HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
   HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
-  HCHECK(h, hipMemcpyAsync(h->h_info.p, h->d_info.p, INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HCHECK(h, hipStreamSynchronize(h->stream));
+  if ((rc = check_info(h, "solve"))) return rc;  // synchronises
   memcpy(out, h->h_stage.p, cnt * sizeof(double));
-  if (h->h_info.as<int>()[INFO_TIMEOUT] != 0) {
-    h->error = "hipfact_solution: dependency wait timed out inside the top-of-tree solve kernel";
-    return HIPFACT_EINTERNAL;
-  }
   return HIPFACT_OK;
+}
+
+int hipfact_check(hipfact_handle* h) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!h->have_plan) return HIPFACT_OK;
+  if ((rc = finish_solve(h))) return rc;
+  return check_info(h, h->solved ? "solve" : "factorisation");
 }
 
 int hipfact_solution_device(hipfact_handle* h, const double** d_sol) {
@@ -1274,16 +1484,14 @@ int hipfact_condition(hipfact_handle* h, double* condition) {
     *condition = 1.0;
     return HIPFACT_OK;
   }
-  hipLaunchKernelGGL(k_pivot_minmax, dim3(64), dim3(FB), 0, h->stream, P.nsuper, h->d_sn.as<SnDesc>(),
-                     h->d_L.as<double>(), h->d_minmax.as<double>());
-  double* hm = reinterpret_cast<double*>(h->h_info.as<char>() + INFO_WORDS * sizeof(int));
-  HCHECK(h, hipMemcpyAsync(hm, h->d_minmax.p, 2 * 64 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  // min / max |d| were left behind the info words by the factorisation
+  unsigned long long* hm = reinterpret_cast<unsigned long long*>(h->h_info.as<char>() + INFO_WORDS * sizeof(int));
+  HCHECK(h, hipMemcpyAsync(hm, minmax_ptr(h), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
-  double lo = 1.7e308, hi = 0.0;
-  for (int b = 0; b < 64; ++b) {
-    lo = std::min(lo, hm[2 * b]);
-    hi = std::max(hi, hm[2 * b + 1]);
-  }
+  const unsigned long long nlo = ~hm[0];
+  double lo, hi;
+  memcpy(&lo, &nlo, 8);
+  memcpy(&hi, &hm[1], 8);
   if (P.saddle) {  // the leaf pivots of the identity block are 1
     lo = std::min(lo, 1.0);
     hi = std::max(hi, 1.0);
@@ -1571,11 +1779,18 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
   int it = 0;
   bool boundary = false;
 
+  // The refinement of a projection is controlled on the device; its control block arrives with
+  // the dot products that follow it.  Only when a projection needed more passes than its graph
+  // carries (ill-conditioned working set) is it continued from here and the products redone.
+  bool cont = false;
   // g0 = P[r0], d0 = -g0
   if ((rc = solve_async(h, h->d_cg_b.as<double>(), h->d_cg_z.as<double>()))) return rc;
-  HCHECK(h, hipMemsetAsync(d, 0, nb, st));
-  hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -1.0, g, 0.0, d);
-  if ((rc = cg_dots(h, n, d, d, r, g, nullptr, nullptr, dots))) return rc;
+  do {
+    HCHECK(h, hipMemsetAsync(d, 0, nb, st));
+    hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -1.0, g, 0.0, d);
+    if ((rc = cg_dots(h, n, d, d, r, g, nullptr, nullptr, dots))) return rc;
+    if ((rc = finish_solve(h, &cont))) return rc;
+  } while (cont);
   double d_nrm_sq = dots[0], r_dot_g = dots[1];
   double z_nrm_sq = 0.0;
   if (!(d_nrm_sq < rel_tol_sq)) {
@@ -1620,7 +1835,10 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
       hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, alpha, Bd, 1.0, r);  // r += alpha B d
       z_nrm_sq = z_next_nrm_sq;
       if ((rc = solve_async(h, h->d_cg_b.as<double>(), h->d_cg_z.as<double>()))) return rc;  // g = P[r]
-      if ((rc = cg_dots(h, n, r, g, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+      do {
+        if ((rc = cg_dots(h, n, r, g, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+        if ((rc = finish_solve(h, &cont))) return rc;
+      } while (cont);
       const double beta = dots[0] / r_dot_g;
       r_dot_g = dots[0];
       hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -1.0, g, beta, d);  // d = -g + beta d
@@ -1635,7 +1853,7 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
   }
   HCHECK(h, hipGetLastError());
   HCHECK(h, hipMemcpyAsync(h->h_stage.p, z, nb, hipMemcpyDeviceToHost, st));
-  HCHECK(h, hipStreamSynchronize(st));
+  if ((rc = check_info(h, "solve"))) return rc;  // synchronises; a timed-out sweep invalidates the step
   memcpy(newton_step, h->h_stage.p, nb);
   if (iterations) *iterations = it;
   return HIPFACT_OK;
@@ -1646,14 +1864,32 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   if (!h || !name) return HIPFACT_EINVAL;
   if (!strcmp(name, "refine_steps")) {
     h->refine_steps = std::max(0, (int)value);
+    h->refine_inline = h->refine_steps;
+    drop_graphs(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "refine_max")) {
+    h->refine_max = std::max(0, (int)value);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "refine_adaptive")) {
     h->refine_adaptive = value != 0.0;
+    drop_graphs(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "refine_tol")) {
     h->refine_tol = value;
+    drop_graphs(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "fail_omega")) {
+    h->fail_omega = value;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "equilibrate")) {  // takes effect at the next factorisation
+    h->equilibrate = value != 0.0;
+    drop_graphs(h);
+    h->factored = false;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "use_graph")) {
@@ -1770,6 +2006,9 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
+  INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
+  INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)
+  INFO("refine_inline", h->refine_inline) INFO("refine_tol", h->refine_tol) INFO("equilibrate", h->equilibrate)
   INFO("factor_top_level", h->ftop_level) INFO("factor_top_count", h->ftop_count) INFO("top_level", h->top_level) INFO("top_count", h->top_count) INFO("solve_timeouts", h->h_info.p ? h->h_info.as<int>()[INFO_TIMEOUT] : 0)
   INFO("use_graph", h->use_graph) INFO("num_graphs", h->graphs.size()) INFO("max_r", P.max_r) INFO("max_w", P.max_w) INFO("refine_steps", h->refine_steps)
   INFO("device", h->device) INFO("nnzM", P.Mi.size()) INFO("nnzA", P.Ar_src.size())
