@@ -132,6 +132,32 @@ struct GraphEntry {
   hipGraphExec_t exec;
 };
 
+// captured graphs of one plan state; owns the executables
+struct GraphList {
+  std::vector<GraphEntry> v;
+  GraphList() = default;
+  GraphList(const GraphList&) = delete;
+  GraphList& operator=(const GraphList&) = delete;
+  GraphList(GraphList&& o) noexcept : v(std::move(o.v)) { o.v.clear(); }
+  GraphList& operator=(GraphList&& o) noexcept {
+    if (this != &o) {
+      clear();
+      v = std::move(o.v);
+      o.v.clear();
+    }
+    return *this;
+  }
+  ~GraphList() { clear(); }
+  void clear() {
+    for (auto& g : v) (void)hipGraphExecDestroy(g.exec);
+    v.clear();
+  }
+  size_t size() const { return v.size(); }
+  std::vector<GraphEntry>::iterator begin() { return v.begin(); }
+  std::vector<GraphEntry>::iterator end() { return v.end(); }
+  void push_back(const GraphEntry& g) { v.push_back(g); }
+};
+
 // Everything that belongs to ONE symbolic plan: the plan, its device image, the numeric arenas
 // and the captured graphs (which hold pointers into exactly these buffers).  The handle IS the
 // active state (it derives from this struct, so h->d_L etc. address the active plan); states of
@@ -156,7 +182,7 @@ struct PlanState {
   int refine_inline = 1;      // correction passes currently carried by the solve graphs
   int seq_at_factor = 0;      // handle's solve_seq at the time of the last factorisation
   bool inline_probe = true;   // the first solve of this factorisation has not been looked at yet
-  std::vector<GraphEntry> graphs;
+  GraphList graphs;
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family
@@ -172,23 +198,11 @@ struct PlanState {
   DevBuf d_xarena;  // posted pivot blocks of the single-launch factorisation (polled by its panel workgroups)
   DevBuf d_ysol;    // polled copy of the solution of M y = t (single-launch backward sweep)
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res;
-  DevBuf d_Ksc, d_Kprod, d_dscale, d_vmap, d_cmap, d_diag_target, d_sidx;
+  DevBuf d_Ksc, d_Kprod, d_dscale, d_vmap, d_cmap, d_diag_target, d_sidx, d_srow;
 
   PlanState() = default;
   PlanState(PlanState&&) = default;
-  PlanState& operator=(PlanState&& o) {
-    if (this != &o) {
-      destroy_graphs();
-      this->~PlanState();
-      new (this) PlanState(std::move(o));
-    }
-    return *this;
-  }
-  void destroy_graphs() {
-    for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
-    graphs.clear();
-  }
-  ~PlanState() { destroy_graphs(); }
+  PlanState& operator=(PlanState&&) = default;
 };
 
 struct hipfact_handle : PlanState {
@@ -198,6 +212,10 @@ struct hipfact_handle : PlanState {
   PlanParams prm;
   std::vector<std::unique_ptr<PlanState>> cache;  // inactive plan states, at most plan_cache_max
   int plan_cache_max = 4;
+  bool assemble_superset = true;  // hipfact_assemble_kkt analyses a superset structure of J instead of K itself
+  bool jdev_valid = false;        // pattern of the Jacobian resident in d_jp / d_ji
+  unsigned long long jdev_hash = 0;
+  int jdev_n = 0, jdev_nnz = 0;
   unsigned long long use_clock = 0;
   long plan_swaps = 0;
   // Iterative refinement on K itself, controlled on the device (RefineCtl): every solve graph holds
@@ -804,7 +822,7 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_ysol.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
   HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), h->stream));
   HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), h->stream));
-  const size_t nb = std::max<size_t>((size_t)P.N * sizeof(double), 16);
+  const size_t nb = std::max<size_t>((size_t)std::max(P.N, h->N_ext) * sizeof(double), 16);
   HCHECK(h, h->d_rhs.ensure(nb));
   HCHECK(h, h->d_sol.ensure(nb));
   HCHECK(h, h->d_res.ensure(nb));
@@ -1042,7 +1060,7 @@ static void solve_m_async(hipfact_handle* h, const int* skip) {
 // numbering, b != z
 static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool acc, const int* skip) {
   const Plan& P = h->plan;
-  if (P.N == 0) return;
+  if (h->N_ext == 0) return;
   if (P.saddle) {
     const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
@@ -1090,7 +1108,15 @@ static void residual_async(hipfact_handle* h, const double* b, const double* z, 
   }
 }
 
-static void drop_graphs(hipfact_handle* h) { h->destroy_graphs(); }
+static void drop_graphs(hipfact_handle* h) { h->graphs.clear(); }
+
+// options that change the plan or the schedule: every cached state is stale
+static void invalidate_plans(hipfact_handle* h) {
+  h->graphs.clear();
+  h->have_plan = false;
+  h->factored = false;
+  h->cache.clear();
+}
 
 // Runs `enqueue` (a function that only queues work on h->stream) through a
 // cached hipGraph; falls back to direct enqueueing when graphs are disabled,
@@ -1148,7 +1174,7 @@ static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
   const double* bb = b;
   if (h->refine_steps > 0 && b == z) {  // keep a private copy of b for the residual
-    HCHECK(h, hipMemcpyAsync(h->d_rhs.p, b, (size_t)P.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->d_rhs.p, b, (size_t)h->N_ext * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     bb = h->d_rhs.as<double>();
   }
   solve_once_async(h, bb, z, false, nullptr);
@@ -1162,8 +1188,7 @@ static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
 
 // Queues a full solve.  No host synchronisation: the refinement loop is controlled on the device.
 static int solve_async(hipfact_handle* h, const double* b, double* z) {
-  const Plan& P = h->plan;
-  if (P.N == 0) return HIPFACT_OK;
+  if (h->N_ext == 0) return HIPFACT_OK;
   if (h->refine_steps > 0 && h->refine_adaptive && h->inline_probe && h->solve_seq > h->seq_at_factor) {
     // Has the previous solve of this factorisation been judged yet?  (A peek at the pinned copy, no
     // synchronisation.)  If its first pass met the tolerance with room to spare, the following
@@ -1225,24 +1250,68 @@ static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
   return HIPFACT_OK;
 }
 
+// word-wise FNV-1a (the patterns are megabytes: this runs at memory speed)
+static unsigned long long hash_ints(const int* p, size_t n, unsigned long long hsh = 1469598103934665603ull) {
+  size_t i = 0;
+  for (; i + 1 < n; i += 2) {
+    unsigned long long w;
+    memcpy(&w, p + i, 8);
+    hsh = (hsh ^ w) * 1099511628211ull;
+  }
+  if (i < n) hsh = (hsh ^ (unsigned long long)(unsigned int)p[i]) * 1099511628211ull;
+  return hsh;
+}
+
+// parks the active plan state in the LRU list (evicting the least recently used one) and leaves a
+// fresh state active
+static void park_active(hipfact_handle* h) {
+  if (h->have_plan && h->plan_cache_max > 0) {
+    if ((int)h->cache.size() >= h->plan_cache_max) {
+      size_t lru = 0;
+      for (size_t i = 1; i < h->cache.size(); ++i)
+        if (h->cache[i]->use_stamp < h->cache[lru]->use_stamp) lru = i;
+      h->cache.erase(h->cache.begin() + (long)lru);
+    }
+    h->cache.emplace_back(new PlanState(std::move(static_cast<PlanState&>(*h))));
+  }
+  static_cast<PlanState&>(*h) = PlanState();
+}
+
+// makes cache[i] the active state (the active one takes its place in the list)
+static void swap_in(hipfact_handle* h, size_t i) {
+  PlanState tmp(std::move(*h->cache[i]));
+  *h->cache[i] = std::move(static_cast<PlanState&>(*h));
+  static_cast<PlanState&>(*h) = std::move(tmp);
+  if (!h->cache[i]->have_plan) h->cache.erase(h->cache.begin() + (long)i);
+  h->plan_swaps++;
+}
+
 static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* rowidx, const double* vals) {
   const long long nnz = N > 0 ? colptr[N] : 0;
-  if (h->have_plan && h->plan.N == N && h->plan.nnzK == nnz &&
-      memcmp(h->plan.Kp.data(), colptr, (size_t)(N + 1) * sizeof(int)) == 0 &&
-      (nnz == 0 || memcmp(h->plan.Ki.data(), rowidx, (size_t)nnz * sizeof(int)) == 0)) {
-    // pattern unchanged.  The saddle classification also depends on the unit
-    // diagonal values; re-check them (n entries)
-    bool ok = true;
-    if (h->plan.saddle && vals)
-      for (int j = 0; j < h->plan.n && ok; ++j) ok = (vals[colptr[j]] == 1.0);
-    if (ok) {
-      h->cache_hits++;
-      return HIPFACT_OK;
+  const unsigned long long hsh = hash_ints(rowidx, (size_t)nnz, hash_ints(colptr, (size_t)N + 1));
+  auto matches = [&](const PlanState& s) {
+    if (!(s.have_plan && !s.from_jacobian && s.plan.N == N && s.plan.nnzK == nnz && s.key_hash == hsh &&
+          memcmp(s.plan.Kp.data(), colptr, (size_t)(N + 1) * sizeof(int)) == 0 &&
+          (nnz == 0 || memcmp(s.plan.Ki.data(), rowidx, (size_t)nnz * sizeof(int)) == 0)))
+      return false;
+    // pattern unchanged.  The saddle classification also depends on the unit diagonal values (n entries)
+    if (s.plan.saddle && vals)
+      for (int j = 0; j < s.plan.n; ++j)
+        if (vals[colptr[j]] != 1.0) return false;
+    return true;
+  };
+  bool hit = matches(*h);
+  for (size_t i = 0; !hit && i < h->cache.size(); ++i)
+    if (matches(*h->cache[i])) {
+      swap_in(h, i);
+      hit = true;
     }
+  h->use_stamp = ++h->use_clock;
+  if (hit) {
+    h->cache_hits++;
+    return HIPFACT_OK;
   }
-  h->have_plan = false;
-  h->factored = false;
-  drop_graphs(h);
+  park_active(h);
   try {
     if (!build_plan(N, colptr, rowidx, vals, h->prm, h->plan)) {
       h->error = h->plan.error;
@@ -1253,6 +1322,9 @@ static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* r
     return HIPFACT_ENOMEM;
   }
   h->analyses++;
+  h->key_hash = hsh;
+  h->N_ext = N;
+  h->use_stamp = h->use_clock;
   int rc = upload_plan(h);
   if (rc) return rc;
   h->have_plan = true;
@@ -1384,7 +1456,7 @@ int hipfact_solve_dense(hipfact_handle* h, const double* rhs) {
   int rc = enter(h);
   if (rc) return rc;
   if ((rc = require_factor(h, "hipfact_solve_dense"))) return rc;
-  const size_t N = (size_t)h->plan.N;
+  const size_t N = (size_t)h->N_ext;
   if (N == 0) return HIPFACT_OK;
   if (!rhs) return HIPFACT_EINVAL;
   HCHECK(h, hipStreamSynchronize(h->stream));  // staging buffer may still be in flight
@@ -1398,7 +1470,7 @@ int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices
   int rc = enter(h);
   if (rc) return rc;
   if ((rc = require_factor(h, "hipfact_solve_sparse"))) return rc;
-  const int N = h->plan.N;
+  const int N = h->N_ext;
   if (dim != N || nnz < 0 || nnz > N || (nnz > 0 && (!indices || !data))) {
     h->error = "hipfact_solve_sparse: rhs dimension does not match the matrix";
     return HIPFACT_EINVAL;
@@ -1432,18 +1504,18 @@ int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol) 
   int rc = enter(h);
   if (rc) return rc;
   if ((rc = require_factor(h, "hipfact_solve_device"))) return rc;
-  if (h->plan.N > 0 && (!d_rhs || !d_sol)) return HIPFACT_EINVAL;
+  if (h->N_ext > 0 && (!d_rhs || !d_sol)) return HIPFACT_EINVAL;
   return solve_async(h, d_rhs, d_sol);
 }
 
 int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
   int rc = enter(h);
   if (rc) return rc;
-  if (!h->solved && h->plan.N > 0) {
+  if (!h->solved && h->N_ext > 0) {
     h->error = "hipfact_solution: no solve has been performed";
     return HIPFACT_ESTATE;
   }
-  if (begin < 0 || end < begin || end > h->plan.N || (end > begin && !out)) {
+  if (begin < 0 || end < begin || end > h->N_ext || (end > begin && !out)) {
     h->error = "hipfact_solution: range outside [0, N]";
     return HIPFACT_EINVAL;
   }
@@ -1514,6 +1586,57 @@ int hipfact_stream(hipfact_handle* h, void** stream) {
 }
 
 // ---------------------------------------------------------------------------
+// Plan for the structure K_s = [I J_s^T; J_s 0] over the constraint rows `cover` (sidx >= 0) of J.
+static int build_superset_plan(hipfact_handle* h, int n, int m_total, const int* jp, const int* ji,
+                               const std::vector<int>& sidx, int ms) {
+  const int jnnz = n > 0 ? jp[n] : 0;
+  const int Ns = n + ms;
+  std::vector<int> kp((size_t)Ns + 1), ki;
+  ki.reserve((size_t)n + jnnz);
+  for (int j = 0; j < n; ++j) {
+    kp[j] = (int)ki.size();
+    ki.push_back(j);
+    for (int q = jp[j]; q < jp[j + 1]; ++q)
+      if (sidx[ji[q]] >= 0) ki.push_back(n + sidx[ji[q]]);
+  }
+  for (int j = n; j <= Ns; ++j) kp[j] = (int)ki.size();
+  try {
+    if (!build_plan(Ns, kp.data(), ki.data(), nullptr, h->prm, h->plan)) {
+      h->error = h->plan.error;
+      return HIPFACT_EINVAL;
+    }
+  } catch (const std::bad_alloc&) {
+    h->error = "out of host memory during analysis";
+    return HIPFACT_ENOMEM;
+  }
+  if (!h->plan.saddle || h->plan.n != n) {
+    h->error = "internal: superset structure not recognised as a saddle matrix";
+    return HIPFACT_EINTERNAL;
+  }
+  h->analyses++;
+  h->from_jacobian = true;
+  h->Jp.assign(jp, jp + n + 1);
+  h->Ji.assign(ji, ji + jnnz);
+  h->sidx = sidx;
+  h->m_struct = ms;
+  h->N_ext = 2 * n + ms;  // capacity of the solve vectors: any working set inside the superset plus all bounds
+  int rc = upload_plan(h);
+  if (rc) return rc;
+  std::vector<int> srow((size_t)std::max(ms, 1), 0);
+  for (int i = 0; i < m_total; ++i)
+    if (sidx[i] >= 0) srow[sidx[i]] = i;
+  std::vector<long long> dt((size_t)std::max(h->plan.m, 1), 0);
+  for (int k = 0; k < h->plan.m; ++k) dt[k] = h->plan.Mtarget[h->plan.Mp[k]];  // the diagonal comes first in every column
+  if ((rc = upload(h, h->d_sidx, h->sidx))) return rc;
+  if ((rc = upload(h, h->d_cmap, srow))) return rc;  // placeholder sizing; d_srow below
+  if ((rc = upload(h, h->d_srow, srow))) return rc;
+  if ((rc = upload(h, h->d_diag_target, dt))) return rc;
+  HCHECK(h, h->d_vmap.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
+  HCHECK(h, h->d_Kprod.ensure(std::max<size_t>((size_t)h->plan.nnzK * sizeof(double), 16)));
+  h->have_plan = true;
+  return HIPFACT_OK;
+}
+
 int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_colptr, const int* j_rowidx,
                          const double* j_vals, const int* var_index, const int* cons_index, int working_set_size,
                          int* k_nnz, int* k_colptr, int* k_rowidx, double* k_vals) {
@@ -1525,55 +1648,150 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
   }
   const int jnnz = n > 0 ? j_colptr[n] : 0;
   const int N = n + working_set_size;
-  int nav = 0;
+  int nav = 0, nac = 0;
   for (int j = 0; j < n; ++j) nav += (var_index[j] >= 0);
+  for (int i = 0; i < m_total; ++i) nac += (cons_index[i] >= 0);
+  if (nav + nac != working_set_size) {
+    h->error = "hipfact_assemble_kkt: working_set_size does not match the index maps";
+    return HIPFACT_EINVAL;
+  }
+  for (int q = 0; q < jnnz; ++q)
+    if (j_rowidx[q] < 0 || j_rowidx[q] >= m_total) {
+      h->error = "hipfact_assemble_kkt: Jacobian row index out of range";
+      return HIPFACT_EINVAL;
+    }
   const size_t cap = (size_t)n + jnnz + nav;  // reserve_aug_jac (standard_aug_jac.c:106-133)
   hipStream_t st = h->stream;
+  HCHECK(h, hipStreamSynchronize(st));  // the buffers below may still be read by queued work
+  const bool want_arrays = k_colptr || k_rowidx || k_vals;
+  // ---- the Jacobian and the working-set maps go to the device (the pattern only when it changed)
+  const unsigned long long jhash = hash_ints(j_rowidx, (size_t)jnnz, hash_ints(j_colptr, (size_t)n + 1));
+  const bool same_pattern = h->jdev_valid && h->jdev_hash == jhash && h->jdev_n == n && h->jdev_nnz == jnnz;
   HCHECK(h, h->d_jp.ensure((size_t)(n + 1) * sizeof(int)));
   HCHECK(h, h->d_ji.ensure(std::max<size_t>((size_t)jnnz * sizeof(int), 16)));
   HCHECK(h, h->d_jx.ensure(std::max<size_t>((size_t)jnnz * sizeof(double), 16)));
   HCHECK(h, h->d_vi.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
   HCHECK(h, h->d_ci.ensure(std::max<size_t>((size_t)m_total * sizeof(int), 16)));
-  HCHECK(h, h->d_cnt.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
-  HCHECK(h, h->d_akp.ensure((size_t)(N + 1) * sizeof(int)));
-  HCHECK(h, h->d_aki.ensure(std::max<size_t>(cap * sizeof(int), 16)));
-  HCHECK(h, h->d_akx.ensure(std::max<size_t>(cap * sizeof(double), 16)));
-  HCHECK(h, hipMemcpyAsync(h->d_jp.p, j_colptr, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-  if (jnnz > 0) {
-    HCHECK(h, hipMemcpyAsync(h->d_ji.p, j_rowidx, (size_t)jnnz * sizeof(int), hipMemcpyHostToDevice, st));
-    HCHECK(h, hipMemcpyAsync(h->d_jx.p, j_vals, (size_t)jnnz * sizeof(double), hipMemcpyHostToDevice, st));
+  if (!same_pattern) {
+    HCHECK(h, hipMemcpyAsync(h->d_jp.p, j_colptr, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (jnnz > 0) HCHECK(h, hipMemcpyAsync(h->d_ji.p, j_rowidx, (size_t)jnnz * sizeof(int), hipMemcpyHostToDevice, st));
+    h->jdev_valid = true;
+    h->jdev_hash = jhash;
+    h->jdev_n = n;
+    h->jdev_nnz = jnnz;
   }
+  if (jnnz > 0) HCHECK(h, hipMemcpyAsync(h->d_jx.p, j_vals, (size_t)jnnz * sizeof(double), hipMemcpyHostToDevice, st));
   if (n > 0) HCHECK(h, hipMemcpyAsync(h->d_vi.p, var_index, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
   if (m_total > 0)
     HCHECK(h, hipMemcpyAsync(h->d_ci.p, cons_index, (size_t)m_total * sizeof(int), hipMemcpyHostToDevice, st));
-  if (n > 0)
-    hipLaunchKernelGGL(k_asm_count, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
-                       h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_cnt.as<int>());
-  hipLaunchKernelGGL(k_asm_scan, dim3(1), dim3(1024), 0, st, n, N, h->d_cnt.as<int>(), h->d_akp.as<int>());
-  if (n > 0)
-    hipLaunchKernelGGL(k_asm_fill, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
-                       h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_akp.as<int>(),
-                       h->d_aki.as<int>(), h->d_akx.as<double>());
-  HCHECK(h, hipGetLastError());
-  // the pattern is needed on the host for the (cached) symbolic analysis
-  std::vector<int> kp(N + 1);
-  HCHECK(h, hipMemcpyAsync(kp.data(), h->d_akp.p, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-  HCHECK(h, hipStreamSynchronize(st));
-  const int nnz = kp[N];
-  if ((size_t)nnz > cap) {
-    h->error = "hipfact_assemble_kkt: internal count mismatch";
-    return HIPFACT_EINTERNAL;
+  // ---- fill_aug_jac on the device: only when the caller asks for K itself, or on the plain path
+  const bool superset = h->assemble_superset && n > 0;
+  std::vector<int> kp, ki;
+  int nnz = 0;
+  if (want_arrays || !superset) {
+    HCHECK(h, h->d_cnt.ensure(std::max<size_t>((size_t)n * sizeof(int), 16)));
+    HCHECK(h, h->d_akp.ensure((size_t)(N + 1) * sizeof(int)));
+    HCHECK(h, h->d_aki.ensure(std::max<size_t>(cap * sizeof(int), 16)));
+    HCHECK(h, h->d_akx.ensure(std::max<size_t>(cap * sizeof(double), 16)));
+    if (n > 0)
+      hipLaunchKernelGGL(k_asm_count, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
+                         h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_cnt.as<int>());
+    hipLaunchKernelGGL(k_asm_scan, dim3(1), dim3(1024), 0, st, n, N, h->d_cnt.as<int>(), h->d_akp.as<int>());
+    if (n > 0)
+      hipLaunchKernelGGL(k_asm_fill, dim3(nblocks(n)), dim3(FB), 0, st, n, h->d_jp.as<int>(), h->d_ji.as<int>(),
+                         h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(), h->d_akp.as<int>(),
+                         h->d_aki.as<int>(), h->d_akx.as<double>());
+    HCHECK(h, hipGetLastError());
+    kp.resize((size_t)N + 1);
+    HCHECK(h, hipMemcpyAsync(kp.data(), h->d_akp.p, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    HCHECK(h, hipStreamSynchronize(st));
+    nnz = kp[N];
+    if ((size_t)nnz > cap) {
+      h->error = "hipfact_assemble_kkt: internal count mismatch";
+      return HIPFACT_EINTERNAL;
+    }
+    ki.resize((size_t)nnz);
+    if (nnz > 0) HCHECK(h, hipMemcpy(ki.data(), h->d_aki.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
+    if (k_colptr) memcpy(k_colptr, kp.data(), (size_t)(N + 1) * sizeof(int));
+    if (k_rowidx && nnz > 0) memcpy(k_rowidx, ki.data(), (size_t)nnz * sizeof(int));
+    if (k_vals && nnz > 0) HCHECK(h, hipMemcpy(k_vals, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+  } else {
+    nnz = n + nav;
+    for (int q = 0; q < jnnz; ++q) nnz += (cons_index[j_rowidx[q]] >= 0);
   }
-  std::vector<int> ki(nnz);
-  if (nnz > 0) HCHECK(h, hipMemcpy(ki.data(), h->d_aki.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
   if (k_nnz) *k_nnz = nnz;
-  if (k_colptr) memcpy(k_colptr, kp.data(), (size_t)(N + 1) * sizeof(int));
-  if (k_rowidx && nnz > 0) memcpy(k_rowidx, ki.data(), (size_t)nnz * sizeof(int));
-  if (k_vals && nnz > 0) HCHECK(h, hipMemcpy(k_vals, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-  // values of the unit diagonal are 1 by construction: pattern-only analysis
-  if ((rc = ensure_plan(h, N, kp.data(), ki.data(), nullptr))) return rc;
-  if (nnz > 0)
-    HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (!superset) {
+    // plain path: K's own pattern is analysed (values of the unit diagonal are 1 by construction)
+    if ((rc = ensure_plan(h, N, kp.data(), ki.data(), nullptr))) return rc;
+    h->maps_on = false;
+    h->N_ext = N;
+    if (nnz > 0)
+      HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = factor_async(h))) return rc;
+    return check_info(h);
+  }
+  // ---- superset path: find a plan whose structure covers the working set's constraint rows
+  auto covers = [&](const PlanState& s) {
+    if (!(s.have_plan && s.from_jacobian && s.plan.n == n && (int)s.sidx.size() == m_total && s.key_hash == jhash &&
+          (int)s.Ji.size() == jnnz && memcmp(s.Jp.data(), j_colptr, (size_t)(n + 1) * sizeof(int)) == 0 &&
+          (jnnz == 0 || memcmp(s.Ji.data(), j_rowidx, (size_t)jnnz * sizeof(int)) == 0)))
+      return false;
+    for (int i = 0; i < m_total; ++i)
+      if (cons_index[i] >= 0 && s.sidx[i] < 0) return false;
+    // a structure far larger than the working set wastes the factorisation on unit rows
+    return 2LL * nac >= s.m_struct || s.m_struct - nac <= 256;
+  };
+  bool hit = covers(*h);
+  for (size_t i = 0; !hit && i < h->cache.size(); ++i)
+    if (covers(*h->cache[i])) {
+      swap_in(h, i);
+      hit = true;
+    }
+  h->use_stamp = ++h->use_clock;
+  if (hit) {
+    h->cache_hits++;
+  } else {
+    // new structure: every row of J when the working set holds most of them (rows then enter and leave
+    // without re-analysis), else the working set's rows plus those of a recent structure of this
+    // Jacobian when that stays close (working sets that oscillate)
+    std::vector<int> sidx((size_t)m_total, -1);
+    std::vector<char> cover((size_t)m_total, 0);
+    int ms = 0;
+    if (2LL * nac >= m_total) {
+      std::fill(cover.begin(), cover.end(), 1);
+    } else {
+      for (int i = 0; i < m_total; ++i) cover[i] = cons_index[i] >= 0;
+      const PlanState* prev = nullptr;
+      auto same_j = [&](const PlanState& s) {
+        return s.have_plan && s.from_jacobian && s.key_hash == jhash && (int)s.sidx.size() == m_total && s.plan.n == n;
+      };
+      if (same_j(*h)) prev = h;
+      for (size_t i = 0; !prev && i < h->cache.size(); ++i)
+        if (same_j(*h->cache[i])) prev = h->cache[i].get();
+      if (prev) {
+        int uni = 0;
+        for (int i = 0; i < m_total; ++i) uni += (cover[i] || prev->sidx[i] >= 0);
+        if (uni <= nac + nac / 4 + 64)
+          for (int i = 0; i < m_total; ++i) cover[i] = cover[i] || prev->sidx[i] >= 0;
+      }
+    }
+    for (int i = 0; i < m_total; ++i)
+      if (cover[i]) sidx[i] = ms++;
+    park_active(h);
+    h->key_hash = jhash;
+    h->use_stamp = h->use_clock;
+    if ((rc = build_superset_plan(h, n, m_total, j_colptr, j_rowidx, sidx, ms))) return rc;
+  }
+  h->maps_on = true;
+  h->N_ext = N;
+  h->n_bounds = nav;
+  const Plan& P = h->plan;
+  hipLaunchKernelGGL(k_struct_fill, dim3(nblocks(std::max(n, h->m_struct))), dim3(FB), 0, st, n, h->m_struct,
+                     h->d_jp.as<int>(), h->d_ji.as<int>(), h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(),
+                     h->d_sidx.as<int>(), h->d_srow.as<int>(), h->d_Kp.as<int>(), h->d_Kval.as<double>(),
+                     h->d_vmap.as<int>(), h->d_cmap.as<int>());
+  HCHECK(h, hipGetLastError());
+  (void)P;
   if ((rc = factor_async(h))) return rc;
   return check_info(h);
 }
@@ -1749,7 +1967,7 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
     h->error = "hipfact_steihaug_solve: needs a factorised saddle matrix and an n x n Hessian on the same handle";
     return HIPFACT_EINVAL;
   }
-  const int N = P.N;
+  const int N = h->N_ext;
   hipStream_t st = h->stream;
   const size_t nb = (size_t)n * sizeof(double);
   HCHECK(h, h->d_cg_b.ensure((size_t)N * sizeof(double)));
@@ -1899,44 +2117,41 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "top_max_fronts")) {  // 0 disables the single-launch top-of-tree solve
     h->top_max_fronts = (int)value;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "factor_top_max")) {  // 0: one launch per phase and level everywhere
     h->factor_top_max = (int)value;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "wide_min_rows")) {
     h->wide_min_rows = (int)value;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "top_prefetch")) {
     h->top_prefetch = value != 0.0;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "pull_max_children")) {  // 0: extend-add always through the separate assembly kernel
     h->pull_max_children = (int)value;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "split_max_fronts")) {
     h->split_max_fronts = (int)value;
-    drop_graphs(h);
-    h->have_plan = false;
-    h->factored = false;
+    invalidate_plans(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "assemble_superset")) {
+    h->assemble_superset = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "plan_cache")) {  // inactive plan states kept (LRU); 0: one pattern at a time
+    h->plan_cache_max = std::max(0, (int)value);
+    while ((int)h->cache.size() > h->plan_cache_max) h->cache.pop_back();
     return HIPFACT_OK;
   }
   if (!strcmp(name, "debug_phases")) {
@@ -1966,8 +2181,7 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   else
     plan_opt = false;
   if (plan_opt) {
-    h->have_plan = false;  // next set_matrix re-analyses
-    h->factored = false;
+    invalidate_plans(h);  // next set_matrix re-analyses
     return HIPFACT_OK;
   }
   h->error = std::string("unknown option: ") + name;
@@ -1999,12 +2213,13 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
     *value = (double)(expr);  \
     return HIPFACT_OK;        \
   }
-  INFO("N", P.N) INFO("n", P.n) INFO("m", P.m) INFO("saddle", P.saddle) INFO("nnzK", P.nnzK) INFO("nnzL", P.nnzL)
+  INFO("N", h->have_plan ? h->N_ext : P.N) INFO("n", P.n) INFO("m", P.m) INFO("saddle", P.saddle) INFO("nnzK", P.nnzK) INFO("nnzL", P.nnzL)
   INFO("nnzL_true", P.nnzL_true) INFO("flops", P.flops) INFO("flops_dense", P.flops_dense) INFO("nsuper", P.nsuper)
   INFO("nlevels", P.nlevels) INFO("nprod", P.nprod) INFO("L_bytes", P.L_size * 8.0) INFO("U_bytes", P.U_size * 8.0)
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
-  INFO("cache_hits", h->cache_hits) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
+  INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

@@ -3137,4 +3137,31 @@ __global__ __launch_bounds__(FB) void k_asm_fill(int n, const int* __restrict__ 
   }
 }
 
+// Values of the structure K_s = [I J_s^T; J_s 0] of a superset plan (same column order as
+// fill_aug_jac without the bound rows): rows of the superset that are not in the working set get
+// zeros, so that the plan of the superset serves every working set inside it without re-analysis.
+// Also refreshes the maps between the structure and the caller's numbering.
+__global__ __launch_bounds__(FB) void k_struct_fill(int n, int ms, const int* __restrict__ jp,
+                                                    const int* __restrict__ ji, const double* __restrict__ jx,
+                                                    const int* __restrict__ var_index,
+                                                    const int* __restrict__ cons_index,
+                                                    const int* __restrict__ sidx, const int* __restrict__ srow,
+                                                    const int* __restrict__ kp, double* __restrict__ kx,
+                                                    int* __restrict__ vmap, int* __restrict__ cmap) {
+  for (int j = blockIdx.x * FB + threadIdx.x; j < n; j += gridDim.x * FB) {
+    int e = kp[j];
+    kx[e++] = 1.0;
+    for (int q = jp[j]; q < jp[j + 1]; ++q) {
+      const int i = ji[q];
+      if (sidx[i] >= 0) kx[e++] = cons_index[i] >= 0 ? jx[q] : 0.0;
+    }
+    const int vi = var_index[j];
+    vmap[j] = vi >= 0 ? n + vi : -1;
+  }
+  for (int s = blockIdx.x * FB + threadIdx.x; s < ms; s += gridDim.x * FB) {
+    const int ci = cons_index[srow[s]];
+    cmap[s] = ci >= 0 ? n + ci : -1;
+  }
+}
+
 }  // namespace hipfact
