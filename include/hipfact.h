@@ -45,8 +45,16 @@ typedef struct hipfact_handle hipfact_handle;
  * (fact/fact_ma57.c:733-807), lapack_data_create (fact/fact_lapack.c:36-50). */
 int hipfact_create(hipfact_handle** out, int device);
 
-/* Replaces SLEQP_FACT_FREE (fact/fact_types.h:23). Nulls *handle. */
+/* Replaces SLEQP_FACT_FREE (fact/fact_types.h:23). Nulls *handle.  Handles are
+ * reference counted like every SLEQP object (sleqp_fact_capture / _release,
+ * fact/fact.c:120-146): the device state is destroyed when the last reference
+ * is freed.  hipfact_spmat objects hold a reference to their handle. */
 int hipfact_free(hipfact_handle** handle);
+
+/* One more reference to the handle (released with hipfact_free): lets a second
+ * SLEQP object (the TR solver of shim/tr_hipfact.c) share the factorisation of
+ * the augmented Jacobian without process-global bookkeeping. */
+int hipfact_retain(hipfact_handle* handle);
 
 /* Thread-local-free error text of the last failing call on this handle (or of
  * hipfact_create when handle == NULL). */
@@ -182,6 +190,38 @@ int hipfact_spmat_mult_device(hipfact_spmat* M, int trans, const double* d_x, do
  * reference, the step is zero when max_iter is exhausted before convergence. */
 int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double* gradient, double trust_radius,
                            double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations);
+
+/* ---- matrix-free Hessian, Lanczos (the reference's default EQP solver) ---- */
+
+/* product = H direction for host n-vectors; returns 0 on success.  The SLEQP
+ * side wraps sleqp_problem_hess_prod (the matrix-free SLEQP_FUNC_HESS_PROD of
+ * pub_func.h:168-172, dispatched at func.c:373-408) with the current
+ * multipliers, shim/tr_hipfact.c. */
+typedef int (*hipfact_hess_prod_fn)(void* user, const double* direction, double* product);
+
+enum
+{
+  HIPFACT_TR_STEIHAUG = 0, /* projected Steihaug CG, tr/steihaug_solver.c:218-496 */
+  HIPFACT_TR_GLTR     = 1  /* generalised Lanczos trust region, what trlib_krylov_min runs (tr/trlib_solver.c:322-352) */
+};
+
+/* Replaces the SleqpTRCallbacks.solve slot (tr/tr_types.h:9-29) for both of the
+ * reference's Krylov solvers with every n-vector resident in HBM.  `hess` is an
+ * explicit lower-triangular Hessian on this handle, or NULL: then `prod` is
+ * called once per iteration with one n-vector crossing PCIe in each direction
+ * (pinned staging).  GLTR continues on the trust-region boundary (Lanczos basis
+ * kept in HBM, tridiagonal subproblem on the host) like trlib, where Steihaug
+ * stops; convergence gamma_{k+1} |h_k| <= rel_tol * ||g||_P as trlib's
+ * tol_rel_i / tol_rel_b (trlib_solver.c:272-275).  tr_dual: multiplier of the
+ * trust-region constraint (GLTR: 0 when interior). */
+int hipfact_tr_solve(hipfact_handle* h, int method, hipfact_spmat* hess, hipfact_hess_prod_fn prod, void* user,
+                     const double* gradient, double trust_radius, double rel_tol, int max_iter, double* newton_step,
+                     double* tr_dual, int* iterations);
+
+/* Host-only: the tridiagonal trust-region subproblem of GLTR (exposed for the tests).
+ * min 1/2 h'Th + gamma0 e1'h, ||h|| <= radius; delta[0..k) diagonal, gamma[1..k) off-diagonal. */
+int hipfact_tridiag_tr(int k, const double* delta, const double* gamma, double gamma0, double radius, double* h,
+                       double* lambda);
 
 /* ---- options / introspection ------------------------------------------- */
 

@@ -8,7 +8,7 @@
  *
  * Hook: in create_aug_jac (trial_point.c:105-108) replace
  *   sleqp_standard_aug_jac_create(star, problem, settings, fact)
- * by sleqp_hipfact_aug_jac_create(star, problem, settings) when
+ * by sleqp_hipfact_aug_jac_create(star, problem, settings, &handle) when
  * SLEQP_FACT_HIPFACT is the configured backend.
  */
 #include "aug_jac_hipfact.h"
@@ -16,7 +16,6 @@
 #include <assert.h>
 
 #ifndef HIPFACT_STANDALONE
-#include "error.h"
 #include "fail.h"
 #include "iterate.h"
 #include "mem.h"
@@ -26,44 +25,30 @@
 
 #include "hipfact.h"
 
-#include <pthread.h>
+#include <stdbool.h>
+#include <string.h>
 
 typedef struct AugJacData
 {
-  struct AugJacData* next; /* registry of live instances (SleqpAugJac is opaque: no data accessor) */
-  SleqpAugJac* owner;
-
   SleqpProblem* problem;
-  hipfact_handle* handle;
+  hipfact_handle* handle; /* one reference; the TR solver of tr_hipfact.c may hold another (hipfact_retain) */
 
   int working_set_size;
   double condition;
   double zero_eps;
 
+  /* "Do not recompute for linear problems & unchanged working set" (standard_aug_jac.c:247-259):
+   * K depends on the constraint Jacobian and on the two index maps only, so the previous maps
+   * stand in for the reference's copy of the working set */
+  bool fixed_jacobian;
+  bool has_factorization;
+  int* prev_var_index;
+  int* prev_cons_index;
+
   int* var_index;  /* num_variables */
   int* cons_index; /* num_constraints */
   double* slice;   /* dense staging for hipfact_solution */
 } AugJacData;
-
-static pthread_mutex_t registry_lock = PTHREAD_MUTEX_INITIALIZER;
-static AugJacData* registry        = NULL;
-
-hipfact_handle*
-sleqp_hipfact_aug_jac_handle(SleqpAugJac* aug_jac)
-{
-  hipfact_handle* handle = NULL;
-  pthread_mutex_lock(&registry_lock);
-  for (AugJacData* it = registry; it; it = it->next)
-  {
-    if (it->owner == aug_jac)
-    {
-      handle = it->handle;
-      break;
-    }
-  }
-  pthread_mutex_unlock(&registry_lock);
-  return handle;
-}
 
 #define HIPFACT_CALL(data, x)                                                  \
   do                                                                           \
@@ -100,10 +85,19 @@ aug_jac_set_iterate(SleqpIterate* iterate, void* data)
     jacobian->cons_index[i] = sleqp_working_set_cons_index(working_set, i);
   }
 
-  jacobian->working_set_size = sleqp_working_set_size(working_set);
-  jacobian->condition        = SLEQP_NONE;
+  if (jacobian->fixed_jacobian && jacobian->has_factorization
+      && memcmp(jacobian->var_index, jacobian->prev_var_index, (size_t)num_variables * sizeof(int)) == 0
+      && memcmp(jacobian->cons_index, jacobian->prev_cons_index, (size_t)num_constraints * sizeof(int)) == 0)
+  {
+    return SLEQP_OKAY;
+  }
 
-  /* assembly + factorisation on the device; K never exists on the host */
+  jacobian->has_factorization = false;
+  jacobian->working_set_size  = sleqp_working_set_size(working_set);
+  jacobian->condition         = SLEQP_NONE;
+
+  /* assembly + factorisation on the device; K never exists on the host.  A working set inside the
+   * structure analysed before costs a numeric refactorisation only (superset plan). */
   HIPFACT_CALL(jacobian,
                hipfact_assemble_kkt(jacobian->handle,
                                     num_variables,
@@ -120,6 +114,10 @@ aug_jac_set_iterate(SleqpIterate* iterate, void* data)
                                     NULL));
 
   HIPFACT_CALL(jacobian, hipfact_condition(jacobian->handle, &jacobian->condition));
+
+  memcpy(jacobian->prev_var_index, jacobian->var_index, (size_t)num_variables * sizeof(int));
+  memcpy(jacobian->prev_cons_index, jacobian->cons_index, (size_t)num_constraints * sizeof(int));
+  jacobian->has_factorization = true;
 
   return SLEQP_OKAY;
 }
@@ -213,20 +211,11 @@ aug_jac_free(void* data)
 {
   AugJacData* jacobian = (AugJacData*)data;
 
-  pthread_mutex_lock(&registry_lock);
-  for (AugJacData** it = &registry; *it; it = &(*it)->next)
-  {
-    if (*it == jacobian)
-    {
-      *it = jacobian->next;
-      break;
-    }
-  }
-  pthread_mutex_unlock(&registry_lock);
-
   hipfact_free(&jacobian->handle);
 
   sleqp_free(&jacobian->slice);
+  sleqp_free(&jacobian->prev_cons_index);
+  sleqp_free(&jacobian->prev_var_index);
   sleqp_free(&jacobian->cons_index);
   sleqp_free(&jacobian->var_index);
 
@@ -238,9 +227,17 @@ aug_jac_free(void* data)
 }
 
 SLEQP_RETCODE
-sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSettings* settings)
+sleqp_hipfact_aug_jac_create(SleqpAugJac** star,
+                             SleqpProblem* problem,
+                             SleqpSettings* settings,
+                             struct hipfact_handle** handle)
 {
   AugJacData* jacobian = NULL;
+
+  if (handle)
+  {
+    *handle = NULL;
+  }
 
   SLEQP_CALL(sleqp_malloc(&jacobian));
 
@@ -250,8 +247,9 @@ sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSet
   const int num_constraints = sleqp_problem_num_cons(problem);
 
   SLEQP_CALL(sleqp_problem_capture(problem));
-  jacobian->problem   = problem;
-  jacobian->condition = SLEQP_NONE;
+  jacobian->problem        = problem;
+  jacobian->condition      = SLEQP_NONE;
+  jacobian->fixed_jacobian = !(sleqp_problem_has_nonlinear_cons(problem));
 
 #ifdef HIPFACT_STANDALONE
   jacobian->zero_eps = sleqp_settings_zero_eps(settings);
@@ -259,16 +257,35 @@ sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSet
   jacobian->zero_eps = sleqp_settings_real_value(settings, SLEQP_SETTINGS_REAL_ZERO_EPS);
 #endif
 
-  SLEQP_CALL(sleqp_alloc_array(&jacobian->var_index, num_variables));
-  SLEQP_CALL(sleqp_alloc_array(&jacobian->cons_index, num_constraints));
+  /* (the reference's allocation macros are comma expressions, pub_mem.h:14-45: parenthesise them) */
+  SLEQP_RETCODE status = (sleqp_alloc_array(&jacobian->var_index, num_variables));
+  if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->cons_index, num_constraints));
+  if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->prev_var_index, num_variables));
+  if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->prev_cons_index, num_constraints));
   /* |W| <= n (pub_working_set.h:12-13): n doubles cover both solution slices */
-  SLEQP_CALL(sleqp_alloc_array(&jacobian->slice, 2 * num_variables + num_constraints));
+  if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->slice, 2 * num_variables + num_constraints));
 
-  const int status = hipfact_create(&jacobian->handle, -1);
+  int hipfact_status = HIPFACT_OK;
 
-  if (status != HIPFACT_OK)
+  if (status == SLEQP_OKAY)
   {
-    sleqp_raise(SLEQP_INTERNAL_ERROR, "Failed to create hipfact backend <%d> (%s)", status, hipfact_last_error(NULL));
+    hipfact_status = hipfact_create(&jacobian->handle, -1);
+  }
+
+  if (status != SLEQP_OKAY || hipfact_status != HIPFACT_OK)
+  {
+    /* nothing allocated above outlives a failed creation */
+    (void)aug_jac_free(jacobian);
+
+    if (status != SLEQP_OKAY)
+    {
+      return status;
+    }
+
+    sleqp_raise(SLEQP_INTERNAL_ERROR,
+                "Failed to create hipfact backend <%d> (%s)",
+                hipfact_status,
+                hipfact_last_error(NULL));
   }
 
   SleqpAugJacCallbacks callbacks = {.set_iterate       = aug_jac_set_iterate,
@@ -280,11 +297,10 @@ sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSet
 
   SLEQP_CALL(sleqp_aug_jac_create(star, problem, &callbacks, jacobian));
 
-  jacobian->owner = *star;
-  pthread_mutex_lock(&registry_lock);
-  jacobian->next = registry;
-  registry       = jacobian;
-  pthread_mutex_unlock(&registry_lock);
+  if (handle)
+  {
+    *handle = jacobian->handle; /* borrowed: hipfact_retain it to keep it beyond the AugJac's life */
+  }
 
   return SLEQP_OKAY;
 }

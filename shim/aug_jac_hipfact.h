@@ -9,14 +9,18 @@
 #include "pub_settings.h"
 #endif
 
+struct hipfact_handle;
+
+/* Created like sleqp_standard_aug_jac_create (aug_jac/standard_aug_jac.c:525-547), without a
+ * SleqpFact: the factorisation lives in a hipfact handle owned by the new object.  `handle`
+ * (may be NULL) receives a borrowed pointer to it for objects that share the factorisation - the
+ * TR solver of tr_hipfact.c takes its own reference with hipfact_retain; no process-global state
+ * connects the two. */
 SLEQP_WARNUNUSED
 SLEQP_RETCODE
-sleqp_hipfact_aug_jac_create(SleqpAugJac** star, SleqpProblem* problem, SleqpSettings* settings);
-
-/* The hipfact handle (device factorisation) behind an augmented Jacobian created above, NULL for any
- * other SleqpAugJac: used by tr_hipfact.c, which runs the projected CG on the same handle. */
-struct hipfact_handle;
-struct hipfact_handle*
-sleqp_hipfact_aug_jac_handle(SleqpAugJac* aug_jac);
+sleqp_hipfact_aug_jac_create(SleqpAugJac** star,
+                             SleqpProblem* problem,
+                             SleqpSettings* settings,
+                             struct hipfact_handle** handle);
 
 #endif /* SLEQP_AUG_JAC_HIPFACT_H */

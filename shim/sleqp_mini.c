@@ -57,7 +57,13 @@ struct SleqpSettings
   double zero_eps;
   double stat_tol;
   int max_newton_iterations;
+  SLEQP_TR_SOLVER tr_solver;
 };
+
+SLEQP_TR_SOLVER
+sleqp_settings_tr_solver(const SleqpSettings* settings) { return settings->tr_solver; }
+void
+sleqp_settings_set_tr_solver(SleqpSettings* settings, SLEQP_TR_SOLVER value) { settings->tr_solver = value; }
 
 SLEQP_RETCODE
 sleqp_settings_create(SleqpSettings** star)
@@ -67,6 +73,7 @@ sleqp_settings_create(SleqpSettings** star)
   (*star)->zero_eps = 1e-20;
   (*star)->stat_tol = 1e-6;
   (*star)->max_newton_iterations = 100;
+  (*star)->tr_solver             = SLEQP_TR_SOLVER_AUTO;
   return SLEQP_OKAY;
 }
 
@@ -401,13 +408,66 @@ struct SleqpProblem
 {
   int refcount;
   int num_vars, num_cons;
+  bool nonlinear_cons;
+  SleqpMiniHessProd hess_prod;
+  void* hess_data;
 };
+
+void
+sleqp_problem_set_hess_prod_mini(SleqpProblem* p, SleqpMiniHessProd callback, void* data)
+{
+  p->hess_prod = callback;
+  p->hess_data = data;
+}
+
+SLEQP_RETCODE
+sleqp_problem_hess_prod(SleqpProblem* p, const SleqpVec* direction, const SleqpVec* cons_duals, SleqpVec* product)
+{
+  if (!p->hess_prod)
+  {
+    sleqp_raise(SLEQP_INTERNAL_ERROR, "mini problem: no Hessian product installed");
+  }
+  double* dir  = calloc((size_t)(p->num_vars > 0 ? p->num_vars : 1), sizeof(double));
+  double* dual = calloc((size_t)(p->num_cons > 0 ? p->num_cons : 1), sizeof(double));
+  double* prod = calloc((size_t)(p->num_vars > 0 ? p->num_vars : 1), sizeof(double));
+  SLEQP_RETCODE status = SLEQP_OKAY;
+  if (!dir || !dual || !prod)
+  {
+    status = SLEQP_ERROR;
+  }
+  else
+  {
+    for (int k = 0; k < direction->nnz; ++k) dir[direction->indices[k]] = direction->data[k];
+    if (cons_duals)
+      for (int k = 0; k < cons_duals->nnz; ++k) dual[cons_duals->indices[k]] = cons_duals->data[k];
+    if (p->hess_prod(dir, dual, prod, p->hess_data) != 0)
+      status = SLEQP_ERROR;
+    else
+      status = sleqp_vec_set_from_raw(product, prod, p->num_vars, 0.0);
+  }
+  free(dir);
+  free(dual);
+  free(prod);
+  if (status != SLEQP_OKAY)
+  {
+    sleqp_raise(SLEQP_INTERNAL_ERROR, "mini problem: Hessian product failed");
+  }
+  return SLEQP_OKAY;
+}
+
+bool
+sleqp_problem_has_nonlinear_cons(SleqpProblem* p) { return p->nonlinear_cons; }
+void
+sleqp_problem_set_nonlinear_cons_mini(SleqpProblem* p, bool value) { p->nonlinear_cons = value; }
 
 SLEQP_RETCODE
 sleqp_problem_create_mini(SleqpProblem** star, int num_vars, int num_cons)
 {
   SLEQP_CALL(sleqp_malloc(star));
   (*star)->refcount = 1;
+  (*star)->nonlinear_cons = true;
+  (*star)->hess_prod      = NULL;
+  (*star)->hess_data      = NULL;
   (*star)->num_vars = num_vars;
   (*star)->num_cons = num_cons;
   return SLEQP_OKAY;

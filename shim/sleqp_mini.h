@@ -107,6 +107,18 @@ int
 sleqp_settings_max_newton_iterations(const SleqpSettings* settings); /* SLEQP_SETTINGS_INT_MAX_NEWTON_ITERATIONS, default 100 */
 SLEQP_RETCODE
 sleqp_settings_set_newton(SleqpSettings* settings, double stat_tol, int max_newton_iterations); /* harness only */
+/* SLEQP_SETTINGS_ENUM_TR_SOLVER (pub_types.h:134-140), default AUTO */
+typedef enum
+{
+  SLEQP_TR_SOLVER_TRLIB = 0,
+  SLEQP_TR_SOLVER_CG,
+  SLEQP_TR_SOLVER_LSQR,
+  SLEQP_TR_SOLVER_AUTO
+} SLEQP_TR_SOLVER;
+SLEQP_TR_SOLVER
+sleqp_settings_tr_solver(const SleqpSettings* settings);
+void
+sleqp_settings_set_tr_solver(SleqpSettings* settings, SLEQP_TR_SOLVER value); /* harness only */
 
 /* ---- sparse vector (public struct, sparse/pub_vec.h:16-25) ---- */
 typedef struct SleqpVec
@@ -237,10 +249,25 @@ int
 sleqp_problem_num_vars(const SleqpProblem* problem);
 int
 sleqp_problem_num_cons(const SleqpProblem* problem);
+/* problem.h:14; the mini problem is nonlinear unless told otherwise */
+bool
+sleqp_problem_has_nonlinear_cons(SleqpProblem* problem);
+void
+sleqp_problem_set_nonlinear_cons_mini(SleqpProblem* problem, bool value);
+/* problem.h:54-59: product = Hessian of the Lagrangian (x, cons_duals) times direction - the matrix-free
+ * SLEQP_FUNC_HESS_PROD of the user (pub_func.h:168-172).  The mini problem forwards to a callback on dense
+ * arrays installed by the test. */
+typedef int (*SleqpMiniHessProd)(const double* direction, const double* cons_duals, double* product, void* data);
+void
+sleqp_problem_set_hess_prod_mini(SleqpProblem* problem, SleqpMiniHessProd callback, void* data);
 SLEQP_RETCODE
 sleqp_problem_capture(SleqpProblem* problem);
 SLEQP_RETCODE
 sleqp_problem_release(SleqpProblem** star);
+
+SLEQP_RETCODE
+sleqp_problem_hess_prod(SleqpProblem* problem, const struct SleqpVec* direction, const struct SleqpVec* cons_duals,
+                        struct SleqpVec* product);
 
 SLEQP_RETCODE
 sleqp_working_set_create(SleqpWorkingSet** star, SleqpProblem* problem);

@@ -25,12 +25,12 @@ ERRORS = {
 
 # every symbol include/hipfact.h declares
 SYMBOLS = [
-    "hipfact_create", "hipfact_free", "hipfact_last_error", "hipfact_set_matrix", "hipfact_solve_sparse",
+    "hipfact_create", "hipfact_free", "hipfact_retain", "hipfact_last_error", "hipfact_set_matrix", "hipfact_solve_sparse",
     "hipfact_solve_dense", "hipfact_solution", "hipfact_condition", "hipfact_refactor_device",
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_check", "hipfact_stream",
     "hipfact_assemble_kkt", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
     "hipfact_spmat_mult_vec", "hipfact_spmat_mult_vec_trans", "hipfact_spmat_mult_vec_sym",
-    "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_set_option", "hipfact_get_info", "hipfact_plan_create",
+    "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_tr_solve", "hipfact_tridiag_tr", "hipfact_set_option", "hipfact_get_info", "hipfact_plan_create",
     "hipfact_plan_free", "hipfact_plan_error", "hipfact_plan_array", "hipfact_plan_scalar",
 ]
 
@@ -56,6 +56,7 @@ def load() -> C.CDLL:
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     lib.hipfact_create.argtypes = [C.POINTER(vp), ci]
     lib.hipfact_free.argtypes = [C.POINTER(vp)]
+    lib.hipfact_retain.argtypes = [vp]
     lib.hipfact_last_error.argtypes = [vp]
     lib.hipfact_last_error.restype = C.c_char_p
     lib.hipfact_set_matrix.argtypes = [vp, ci, vp, vp, vp]
@@ -78,6 +79,8 @@ def load() -> C.CDLL:
     lib.hipfact_spmat_mult_vec_sym.argtypes = [vp, vp, vp]
     lib.hipfact_spmat_mult_device.argtypes = [vp, ci, vp, vp]
     lib.hipfact_steihaug_solve.argtypes = [vp, vp, vp, cd, cd, ci, vp, C.POINTER(cd), C.POINTER(ci)]
+    lib.hipfact_tr_solve.argtypes = [vp, ci, vp, vp, vp, vp, cd, cd, ci, vp, C.POINTER(cd), C.POINTER(ci)]
+    lib.hipfact_tridiag_tr.argtypes = [ci, vp, vp, cd, cd, vp, C.POINTER(cd)]
     lib.hipfact_set_option.argtypes = [vp, C.c_char_p, cd]
     lib.hipfact_get_info.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
     lib.hipfact_plan_create.argtypes = [ci, vp, vp, vp, C.POINTER(vp)]

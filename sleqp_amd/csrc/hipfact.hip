@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 #include "../../include/hipfact.h"
 #include "device_types.h"
 #include "plan.h"
+#include "tridiag_tr.h"
 
 // single translation unit: the kernels are compiled together with their launcher
 #include "kernels.hip"
@@ -206,6 +208,7 @@ struct PlanState {
 };
 
 struct hipfact_handle : PlanState {
+  std::atomic<int> refcount{1};
   int device = 0;
   hipStream_t stream = nullptr;
   std::string error;
@@ -259,7 +262,8 @@ struct hipfact_handle : PlanState {
   DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
   // projected CG
   DevBuf d_cg_b, d_cg_z, d_cg_vec, d_cg_dots;
-  PinBuf h_cg_dots;
+  PinBuf h_cg_dots, h_hv;
+  DevBuf d_lz_Q, d_lz_b, d_lz_coef;  // generalised Lanczos: basis (n x cap), three rotating right-hand sides, coefficients
 };
 
 struct hipfact_spmat {
@@ -1396,17 +1400,25 @@ int hipfact_create(hipfact_handle** out, int device) {
   return HIPFACT_OK;
 }
 
+int hipfact_retain(hipfact_handle* h) {
+  if (!h) return HIPFACT_EINVAL;
+  h->refcount.fetch_add(1);
+  return HIPFACT_OK;
+}
+
 int hipfact_free(hipfact_handle** handle) {
   if (!handle || !*handle) return HIPFACT_OK;
   hipfact_handle* h = *handle;
+  *handle = nullptr;
+  if (h->refcount.fetch_sub(1) > 1) return HIPFACT_OK;  // other owners remain
   (void)hipSetDevice(h->device);
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
+    h->cache.clear();
     (void)hipStreamDestroy(h->stream);
   }
   delete h;
-  *handle = nullptr;
   return HIPFACT_OK;
 }
 
@@ -1813,6 +1825,7 @@ int hipfact_spmat_create(hipfact_handle* h, int num_rows, int num_cols, const in
   hipfact_spmat* M = new (std::nothrow) hipfact_spmat();
   if (!M) return HIPFACT_ENOMEM;
   M->h = h;
+  h->refcount.fetch_add(1);  // released by hipfact_spmat_free (or by `fail` below)
   M->rows = num_rows;
   M->cols = num_cols;
   M->nnz = nnz;
@@ -1830,6 +1843,7 @@ int hipfact_spmat_create(hipfact_handle* h, int num_rows, int num_cols, const in
   }
   auto fail = [&](int code) {
     delete M;
+    h->refcount.fetch_sub(1);  // the caller still holds its own reference
     return code;
   };
   hipStream_t st = h->stream;
@@ -1883,9 +1897,12 @@ int hipfact_spmat_update_values(hipfact_spmat* M, const double* vals) {
 
 int hipfact_spmat_free(hipfact_spmat** M) {
   if (M && *M) {
-    (void)hipSetDevice((*M)->h->device);
+    hipfact_handle* owner = (*M)->h;
+    (void)hipSetDevice(owner->device);
+    (void)hipStreamSynchronize(owner->stream);
     delete *M;
     *M = nullptr;
+    (void)hipfact_free(&owner);  // the matrix's reference to its handle
   }
   return HIPFACT_OK;
 }
@@ -1955,18 +1972,51 @@ static int cg_dots(hipfact_handle* h, int n, const double* x0, const double* y0,
   return HIPFACT_OK;
 }
 
-int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double* gradient, double trust_radius,
-                           double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations) {
-  int rc = enter(h);
-  if (rc) return rc;
-  if ((rc = require_factor(h, "hipfact_steihaug_solve"))) return rc;
+// Hessian of the Lagrangian as an operator: an explicit matrix resident in HBM, or the caller's
+// matrix-free product (SLEQP_FUNC_HESS_PROD behind sleqp_problem_hess_prod, func.c:373-408).  The
+// matrix-free form moves one n-vector down and one up per product through pinned staging; every
+// other vector of the Krylov loop stays on the device.
+struct HessOp {
+  hipfact_spmat* hess;
+  hipfact_hess_prod_fn prod;
+  void* user;
+};
+
+static int apply_hess(hipfact_handle* h, const HessOp& op, int n, const double* d_in, double* d_out) {
+  if (op.hess) return hipfact_spmat_mult_device(op.hess, 2, d_in, d_out);
+  const size_t nb = (size_t)n * sizeof(double);
+  HCHECK(h, h->h_hv.ensure(2 * nb + 16));
+  double* hv = h->h_hv.as<double>();
+  HCHECK(h, hipMemcpyAsync(hv, d_in, nb, hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  if (op.prod(op.user, hv, hv + n) != 0) {
+    h->error = "Hessian product callback failed";
+    return HIPFACT_EINTERNAL;
+  }
+  HCHECK(h, hipMemcpyAsync(d_out, hv + n, nb, hipMemcpyHostToDevice, h->stream));
+  return HIPFACT_OK;
+}
+
+static int tr_args_ok(hipfact_handle* h, const HessOp& op, const double* gradient, double* newton_step,
+                      double trust_radius, const char* who) {
   const Plan& P = h->plan;
   const int n = P.saddle ? P.n : 0;
-  if (!P.saddle || !hess || hess->h != h || hess->rows != n || hess->cols != n || !gradient || !newton_step ||
-      !(trust_radius > 0.0)) {
-    h->error = "hipfact_steihaug_solve: needs a factorised saddle matrix and an n x n Hessian on the same handle";
+  const bool hess_ok = op.hess ? (op.hess->h == h && op.hess->rows == n && op.hess->cols == n) : op.prod != nullptr;
+  if (!P.saddle || !hess_ok || !gradient || !newton_step || !(trust_radius > 0.0)) {
+    h->error = std::string(who) + ": needs a factorised saddle matrix and an n x n Hessian (explicit, on the same "
+                                  "handle, or a product callback)";
     return HIPFACT_EINVAL;
   }
+  return HIPFACT_OK;
+}
+
+static int steihaug_impl(hipfact_handle* h, const HessOp& op, const double* gradient, double trust_radius,
+                         double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations) {
+  int rc;
+  if ((rc = require_factor(h, "hipfact_steihaug_solve"))) return rc;
+  if ((rc = tr_args_ok(h, op, gradient, newton_step, trust_radius, "hipfact_steihaug_solve"))) return rc;
+  const Plan& P = h->plan;
+  const int n = P.n;
   const int N = h->N_ext;
   hipStream_t st = h->stream;
   const size_t nb = (size_t)n * sizeof(double);
@@ -2021,7 +2071,7 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
       }
       if (fabs(r_dot_g) < rel_tol_sq) break;  // interior solution p = z
       // B d, d^T B d, z^T d
-      if ((rc = hipfact_spmat_mult_device(hess, 2, d, Bd))) return rc;
+      if ((rc = apply_hess(h, op, n, d, Bd))) return rc;
       if ((rc = cg_dots(h, n, d, Bd, z, d, d, d, dots))) return rc;
       const double dBd = dots[0], z_dot_d = dots[1];
       d_nrm_sq = dots[2];
@@ -2064,7 +2114,7 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
   }
   if (boundary && tr_dual) {
     // steihaug_tr_dual (steihaug_solver.c:187-216)
-    if ((rc = hipfact_spmat_mult_device(hess, 2, z, Bd))) return rc;
+    if ((rc = apply_hess(h, op, n, z, Bd))) return rc;
     if ((rc = cg_dots(h, n, z, Bd, z, grad, nullptr, nullptr, dots))) return rc;
     const double comb = dots[0] + dots[1];
     *tr_dual = comb < 0.0 ? (-comb) / rad_sq : 0.0;
@@ -2075,6 +2125,165 @@ int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double*
   memcpy(newton_step, h->h_stage.p, nb);
   if (iterations) *iterations = it;
   return HIPFACT_OK;
+}
+
+int hipfact_steihaug_solve(hipfact_handle* h, hipfact_spmat* hess, const double* gradient, double trust_radius,
+                           double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!hess) {
+    h->error = "hipfact_steihaug_solve: no Hessian";
+    return HIPFACT_EINVAL;
+  }
+  const HessOp op = {hess, nullptr, nullptr};
+  return steihaug_impl(h, op, gradient, trust_radius, rel_tol, max_iter, newton_step, tr_dual, iterations);
+}
+
+// Generalised Lanczos trust-region method (GLTR: Gould, Lucidi, Roma, Toint 1999), the algorithm the
+// reference runs through trlib_krylov_min (tr/trlib_solver.c:322-352) with the null-space projection as
+// preconditioner.  Preconditioned Lanczos with M^-1 = P (the factorised KKT projection of this handle):
+//     t_0 = g,  y_k = P t_k,  gamma_k = sqrt(t_k . y_k),  q_k = y_k / gamma_k
+//     delta_k = q_k . H q_k
+//     t_{k+1} = H q_k - (delta_k / gamma_k) t_k - (gamma_k / gamma_{k-1}) t_{k-1}
+// and after every step the trust-region problem on the tridiagonal T_k (host, tridiag_tr.cpp):
+//     min 1/2 h^T T_k h + gamma_0 e_1^T h,  ||h|| <= radius,        s = Q_k h.
+// While the solution is interior this is the CG iterate; on the boundary the iteration simply goes on
+// (Steihaug stops there) until gamma_{k+1} |h_k| <= max(abs_tol, rel_tol gamma_0) - trlib's tests for
+// the interior and the boundary case (tol_rel_i / tol_rel_b, trlib_solver.c:272-275).  Negative curvature
+// and the hard case are handled inside the tridiagonal solve.  All n-vectors (t, y, H q and the basis Q,
+// n x (iterations + 1)) stay in HBM; the host sees two scalars per iteration.
+static int gltr_impl(hipfact_handle* h, const HessOp& op, const double* gradient, double trust_radius, double rel_tol,
+                     int max_iter, double* newton_step, double* tr_dual, int* iterations) {
+  int rc;
+  if ((rc = require_factor(h, "hipfact_tr_solve"))) return rc;
+  if ((rc = tr_args_ok(h, op, gradient, newton_step, trust_radius, "hipfact_tr_solve"))) return rc;
+  const Plan& P = h->plan;
+  const int n = P.n;
+  const int N = h->N_ext;
+  hipStream_t st = h->stream;
+  const size_t nb = (size_t)n * sizeof(double);
+  const int cap = (max_iter >= 0 ? std::min(max_iter, n) : std::min(n, 1000)) + 1;
+  HCHECK(h, h->d_lz_Q.ensure(std::max<size_t>((size_t)cap * nb, 16)));
+  HCHECK(h, h->d_lz_b.ensure(std::max<size_t>((size_t)3 * N * sizeof(double), 16)));
+  HCHECK(h, h->d_lz_coef.ensure((size_t)cap * sizeof(double)));
+  HCHECK(h, h->d_cg_z.ensure(std::max<size_t>((size_t)N * sizeof(double), 16)));
+  HCHECK(h, h->d_cg_vec.ensure(4 * nb + 64));
+  HCHECK(h, h->d_cg_dots.ensure(3 * DOT_BLOCKS * sizeof(double)));
+  HCHECK(h, h->h_cg_dots.ensure(3 * DOT_BLOCKS * sizeof(double)));
+  HCHECK(h, hipStreamSynchronize(st));
+  HCHECK(h, h->h_stage.ensure(std::max(nb, (size_t)cap * sizeof(double))));
+  double* Q = h->d_lz_Q.as<double>();
+  double* tb[3] = {h->d_lz_b.as<double>(), h->d_lz_b.as<double>() + N, h->d_lz_b.as<double>() + 2 * (size_t)N};
+  const double* y = h->d_cg_z.as<double>();  // head of the KKT solution = P t
+  double* Hq = h->d_cg_vec.as<double>();
+  double* s = Hq + n;
+  const int vb = nblocks(n);
+  if (tr_dual) *tr_dual = 0.0;
+  if (iterations) *iterations = 0;
+  if (n == 0) return HIPFACT_OK;
+  memcpy(h->h_stage.p, gradient, nb);
+  HCHECK(h, hipMemsetAsync(h->d_lz_b.p, 0, (size_t)3 * N * sizeof(double), st));  // the tails [.; 0] stay zero
+  HCHECK(h, hipMemcpyAsync(tb[0], h->h_stage.p, nb, hipMemcpyHostToDevice, st));
+  std::vector<double> delta, gamma, hvec;
+  double dots[3];
+  bool cont = false;
+  // y_0 = P t_0, gamma_0
+  if ((rc = solve_async(h, tb[0], h->d_cg_z.as<double>()))) return rc;
+  do {
+    if ((rc = cg_dots(h, n, tb[0], y, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+    if ((rc = finish_solve(h, &cont))) return rc;
+  } while (cont);
+  const double gamma0 = dots[0] > 0.0 ? sqrt(dots[0]) : 0.0;
+  auto finish_zero = [&]() {
+    memset(newton_step, 0, nb);
+    return HIPFACT_OK;
+  };
+  if (!(gamma0 > 0.0) || !(gamma0 < 1.7e308)) {
+    if (gamma0 == 0.0) return finish_zero();
+    h->error = "hipfact_tr_solve: non-finite projected gradient";
+    return HIPFACT_EINTERNAL;
+  }
+  const double tol = rel_tol * gamma0;
+  hipLaunchKernelGGL(k_scale_to, dim3(vb), dim3(FB), 0, st, n, 1.0 / gamma0, y, Q);
+  // Only P t_k ever enters the recurrence, so t_k is replaced by y_k = P t_k once it has been projected
+  // (the "residual update" of Gould, Hribar, Nocedal 2001): the components of H q in the range of A^T would
+  // otherwise pile up in t, and the projection of a vector that is mostly range space loses the accuracy
+  // of its null-space part.
+  HCHECK(h, hipMemcpyAsync(tb[0], y, nb, hipMemcpyDeviceToDevice, st));
+  gamma.push_back(gamma0);  // gamma[k] = ||t_k||_P; gamma[0] is not part of T
+  double lambda = 0.0;
+  int cur = 0, k = 0;  // tb[cur] = t_k, tb[(cur + 2) % 3] = t_{k-1}
+  const int kmax = cap - 1;
+  for (k = 0; k < kmax; ++k) {
+    const double* q = Q + (size_t)k * n;
+    if ((rc = apply_hess(h, op, n, q, Hq))) return rc;
+    if ((rc = cg_dots(h, n, q, Hq, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+    delta.push_back(dots[0]);
+    // T_k is complete: trust-region problem on the tridiagonal
+    hvec.assign((size_t)k + 1, 0.0);
+    if (tridiag_tr_solve(k + 1, delta.data(), gamma.data(), gamma0, trust_radius, hvec.data(), &lambda) != 0) {
+      h->error = "hipfact_tr_solve: tridiagonal trust-region subproblem failed";
+      return HIPFACT_EINTERNAL;
+    }
+    // t_{k+1} = H q_k - (delta_k / gamma_k) t_k - (gamma_k / gamma_{k-1}) t_{k-1}
+    double* tn = tb[(cur + 1) % 3];
+    HCHECK(h, hipMemcpyAsync(tn, Hq, nb, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -delta[k] / gamma[k], tb[cur], 1.0, tn);
+    if (k > 0)
+      hipLaunchKernelGGL(k_axpby, dim3(vb), dim3(FB), 0, st, n, -gamma[k] / gamma[k - 1], tb[(cur + 2) % 3], 1.0, tn);
+    if ((rc = solve_async(h, tn, h->d_cg_z.as<double>()))) return rc;
+    do {
+      if ((rc = cg_dots(h, n, tn, y, nullptr, nullptr, nullptr, nullptr, dots))) return rc;
+      if ((rc = finish_solve(h, &cont))) return rc;
+    } while (cont);
+    const double gnext = dots[0] > 0.0 ? sqrt(dots[0]) : 0.0;
+    if (!(gnext == gnext)) {
+      h->error = "hipfact_tr_solve: non-finite Lanczos vector";
+      return HIPFACT_EINTERNAL;
+    }
+    gamma.push_back(gnext);
+    HCHECK(h, hipMemcpyAsync(tn, y, nb, hipMemcpyDeviceToDevice, st));  // t_{k+1} := P t_{k+1}
+    cur = (cur + 1) % 3;
+    // converged (interior: CG residual; boundary: trlib's test), or the Krylov space is exhausted
+    if (gnext * fabs(hvec[k]) <= tol || gnext <= 1e-14 * gamma0) {
+      ++k;
+      break;
+    }
+    if (k + 1 < kmax) hipLaunchKernelGGL(k_scale_to, dim3(vb), dim3(FB), 0, st, n, 1.0 / gnext, y, Q + (size_t)(k + 1) * n);
+  }
+  const int dim = (int)hvec.size();
+  if (dim == 0) return finish_zero();
+  // s = Q h
+  HCHECK(h, hipStreamSynchronize(st));
+  memcpy(h->h_stage.p, hvec.data(), (size_t)dim * sizeof(double));
+  HCHECK(h, hipMemcpyAsync(h->d_lz_coef.p, h->h_stage.p, (size_t)dim * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_combine, dim3(vb), dim3(FB), 0, st, n, dim, Q, h->d_lz_coef.as<double>(), s);
+  HCHECK(h, hipGetLastError());
+  HCHECK(h, hipStreamSynchronize(st));
+  HCHECK(h, hipMemcpyAsync(h->h_stage.p, s, nb, hipMemcpyDeviceToHost, st));
+  if ((rc = check_info(h, "solve"))) return rc;  // synchronises
+  memcpy(newton_step, h->h_stage.p, nb);
+  if (tr_dual) *tr_dual = lambda;
+  if (iterations) *iterations = std::min(k, dim);
+  return HIPFACT_OK;
+}
+
+int hipfact_tr_solve(hipfact_handle* h, int method, hipfact_spmat* hess, hipfact_hess_prod_fn prod, void* user,
+                     const double* gradient, double trust_radius, double rel_tol, int max_iter, double* newton_step,
+                     double* tr_dual, int* iterations) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!hess && !prod) {
+    h->error = "hipfact_tr_solve: neither an explicit Hessian nor a product callback";
+    return HIPFACT_EINVAL;
+  }
+  const HessOp op = {hess, hess ? nullptr : prod, user};
+  if (method == HIPFACT_TR_STEIHAUG)
+    return steihaug_impl(h, op, gradient, trust_radius, rel_tol, max_iter, newton_step, tr_dual, iterations);
+  if (method == HIPFACT_TR_GLTR)
+    return gltr_impl(h, op, gradient, trust_radius, rel_tol, max_iter, newton_step, tr_dual, iterations);
+  h->error = "hipfact_tr_solve: unknown method";
+  return HIPFACT_EINVAL;
 }
 
 // ---------------------------------------------------------------------------

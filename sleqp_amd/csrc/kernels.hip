@@ -2995,6 +2995,21 @@ __global__ __launch_bounds__(FB) void k_dots3(int n, const double* __restrict__ 
   }
 }
 
+// y = a x
+__global__ __launch_bounds__(FB) void k_scale_to(int n, double a, const double* __restrict__ x, double* __restrict__ y) {
+  for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) y[i] = a * x[i];
+}
+
+// s = Q c: Q is n x k column-major (the Lanczos basis kept in HBM), c on the device; fixed summation order
+__global__ __launch_bounds__(FB) void k_combine(int n, int k, const double* __restrict__ Q,
+                                                const double* __restrict__ c, double* __restrict__ s) {
+  for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) {
+    double acc = 0.0;
+    for (int j = 0; j < k; ++j) acc += c[j] * Q[i + (long long)j * n];
+    s[i] = acc;
+  }
+}
+
 // y = a x + b y
 __global__ __launch_bounds__(FB) void k_axpby(int n, double a, const double* __restrict__ x, double b,
                                               double* __restrict__ y) {

@@ -38,7 +38,7 @@ def shim(hipfact_lib):
 
 def test_shim_exports_reference_entry_points(shim):
     for name in ["sleqp_fact_create_default", "sleqp_fact_hipfact_create", "sleqp_hipfact_aug_jac_create",
-                 "sleqp_hipfact_aug_jac_handle", "sleqp_hipfact_tr_solver_create", "sleqp_hipfact_tr_bind",
+                 "sleqp_hipfact_tr_solver_create", "sleqp_hipfact_tr_bind", "sleqp_problem_hess_prod",
                  "sleqp_hipfact_tr_set_hessian", "sleqp_tr_solver_solve", "sleqp_tr_solver_release",
                  "sleqp_fact_set_matrix", "sleqp_fact_solve", "sleqp_fact_solution", "sleqp_fact_cond",
                  "sleqp_fact_flags", "sleqp_fact_release"]:
@@ -140,7 +140,7 @@ def test_aug_jac_shim_against_golden(shim, c):
             assert shim.sleqp_working_set_add_cons(ws, int(i), 1) == 0
     W = c.N - c.n
     assert shim.sleqp_working_set_size(ws) == W
-    assert shim.sleqp_hipfact_aug_jac_create(C.byref(aug), problem, settings) == 0, shim.sleqp_error_msg()
+    assert shim.sleqp_hipfact_aug_jac_create(C.byref(aug), problem, settings, None) == 0, shim.sleqp_error_msg()
     assert shim.sleqp_aug_jac_set_iterate(aug, iterate) == 0, shim.sleqp_error_msg()
     g = _vec(shim, c.n, c.g_idx, c.g_dat)
     sol = C.POINTER(SleqpVecC)()
@@ -170,27 +170,10 @@ def test_aug_jac_shim_against_golden(shim, c):
     shim.sleqp_settings_release(C.byref(settings))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("radius", [0.3, 1e3])
-def test_tr_solver_shim_against_oracle(shim, radius):
-    """SleqpTRCallbacks on the device (shim/tr_hipfact.c): sleqp_tr_solver_solve with the hipfact
-    augmented Jacobian reproduces steihaug_solver_solve (oracle restatement) — step, iteration
-    behaviour at the trust-region boundary and in the interior."""
-    import scipy.sparse as sp
+HESS_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
-    import oracle
-    from sleqp_amd import synth
 
-    n, m = 300, 120
-    J = synth.uniform_jacobian(n, m, 4, 7)
-    vi, ci, W = synth.working_set_all_rows(n, m, 0.05, 7)
-    B = sp.random(n, n, density=0.02, random_state=3)
-    HL = sp.tril((B @ B.T + 0.5 * sp.eye(n)).tocsc(), format="csc")
-    HL.sort_indices()
-    g = np.random.default_rng(5).standard_normal(n)
-    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
-    want, _ = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius)
-
+def _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver, stat_tol=1e-6, max_iter=100, linear=False):
     class Case:  # what _fill_jac reads
         pass
 
@@ -198,7 +181,11 @@ def test_tr_solver_shim_against_oracle(shim, radius):
     c.n, c.jp, c.ji, c.jx = n, J.indptr, J.indices, J.data
     settings, problem, iterate, aug = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
     assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    shim.sleqp_settings_set_tr_solver(settings, tr_solver)
+    assert shim.sleqp_settings_set_newton(settings, C.c_double(stat_tol), max_iter) == 0
     assert shim.sleqp_problem_create_mini(C.byref(problem), n, m) == 0
+    if linear:
+        shim.sleqp_problem_set_nonlinear_cons_mini(problem, False)
     assert shim.sleqp_iterate_create_mini(C.byref(iterate), problem) == 0
     _fill_jac(shim, shim.sleqp_iterate_cons_jac(iterate), c)
     ws = C.c_void_p(shim.sleqp_iterate_working_set(iterate))
@@ -208,22 +195,103 @@ def test_tr_solver_shim_against_oracle(shim, radius):
     for i in np.argsort(np.where(ci >= 0, ci, 1 << 30)):
         if ci[i] >= 0:
             assert shim.sleqp_working_set_add_cons(ws, int(i), 1) == 0
-    assert shim.sleqp_hipfact_aug_jac_create(C.byref(aug), problem, settings) == 0, shim.sleqp_error_msg()
+    handle = C.c_void_p()
+    assert shim.sleqp_hipfact_aug_jac_create(C.byref(aug), problem, settings, C.byref(handle)) == 0, shim.sleqp_error_msg()
+    assert handle
     assert shim.sleqp_aug_jac_set_iterate(aug, iterate) == 0, shim.sleqp_error_msg()
-    shim.sleqp_hipfact_aug_jac_handle.restype = C.c_void_p
-    assert shim.sleqp_hipfact_aug_jac_handle(aug)
+    return settings, problem, iterate, aug, handle
 
-    tr, ctl, H = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    assert shim.sleqp_hipfact_tr_solver_create(C.byref(tr), C.byref(ctl), problem, settings) == 0
-    assert shim.sleqp_hipfact_tr_bind(ctl, aug) == 0, shim.sleqp_error_msg()
-    assert shim.sleqp_mat_create(C.byref(H), n, n, max(HL.nnz, 1)) == 0
+
+def _tr_teardown(shim, settings, problem, iterate, aug):
+    assert shim.sleqp_aug_jac_release(C.byref(aug)) == 0
+    shim.sleqp_iterate_release(C.byref(iterate))
+    shim.sleqp_problem_release(C.byref(problem))
+    shim.sleqp_settings_release(C.byref(settings))
+
+
+def _push_matrix(shim, M):
+    H = C.c_void_p()
+    n = M.shape[1]
+    assert shim.sleqp_mat_create(C.byref(H), M.shape[0], n, max(M.nnz, 1)) == 0
     for j in range(n):
         assert shim.sleqp_mat_push_col(H, j) == 0
-        for e in range(HL.indptr[j], HL.indptr[j + 1]):
-            assert shim.sleqp_mat_push(H, int(HL.indices[e]), j, C.c_double(float(HL.data[e]))) == 0
-    assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0, shim.sleqp_error_msg()
-    assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0  # same pattern: values-only path
+        for e in range(M.indptr[j], M.indptr[j + 1]):
+            assert shim.sleqp_mat_push(H, int(M.indices[e]), j, C.c_double(float(M.data[e]))) == 0
+    return H
 
+
+def _exact_tr_step(A_W, Hm, g, radius):
+    """Exact solution of min g's + 1/2 s'Hs, A_W s = 0, ||s|| <= radius (dense, eigen-decomposition of the
+    reduced Hessian): the point the Lanczos method converges to."""
+    import scipy.linalg as sla
+
+    Z = sla.null_space(A_W.toarray()) if A_W.shape[0] else np.eye(len(g))
+    Hr = Z.T @ (Hm @ Z)
+    gr = Z.T @ g
+    lam, V = np.linalg.eigh(Hr)
+    gt = V.T @ gr
+
+    def step(mu):
+        return -gt / (lam + mu)
+
+    if lam[0] > 0 and np.linalg.norm(step(0.0)) <= radius:
+        return Z @ (V @ step(0.0)), 0.0
+    lo = max(0.0, -lam[0]) + 1e-14
+    hi = lo + 1.0
+    while np.linalg.norm(step(hi)) > radius:
+        hi = lo + 2 * (hi - lo)
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if np.linalg.norm(step(mid)) > radius:
+            lo = mid
+        else:
+            hi = mid
+    return Z @ (V @ step(hi)), hi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0.3, 1e3])
+@pytest.mark.parametrize("matrix_free", [False, True])
+def test_tr_solver_shim_steihaug_against_oracle(shim, hipfact_lib, radius, matrix_free):
+    """SleqpTRCallbacks on the device, TR_SOLVER = CG: sleqp_tr_solver_solve reproduces
+    steihaug_solver_solve (oracle restatement) with the Hessian as an explicit matrix in HBM and as
+    the problem's matrix-free product (sleqp_problem_hess_prod, func.c:373-408)."""
+    import scipy.sparse as sp
+
+    import oracle
+    from sleqp_amd import synth
+
+    n, m = 300, 120
+    J = synth.uniform_jacobian(n, m, 4, 7)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.05, 7)
+    B = sp.random(n, n, density=0.02, random_state=3)
+    Hm = (B @ B.T + 0.5 * sp.eye(n)).tocsc()
+    HL = sp.tril(Hm, format="csc")
+    HL.sort_indices()
+    g = np.random.default_rng(5).standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    stat_tol = 1e-6 if radius < 100 else 1e-4
+    want, _ = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius,
+                                                        stat_tol=stat_tol)
+    settings, problem, iterate, aug, handle = _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver=1, stat_tol=stat_tol)
+    calls = []
+
+    def hess_prod(direction, duals, product, _):
+        d = np.ctypeslib.as_array(direction, shape=(n,))
+        np.ctypeslib.as_array(product, shape=(n,))[:] = Hm @ d
+        calls.append(1)
+        return 0
+
+    cb = HESS_CB(hess_prod)
+    shim.sleqp_problem_set_hess_prod_mini(problem, cb, None)
+    tr, ctl = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_hipfact_tr_solver_create(C.byref(tr), C.byref(ctl), problem, settings) == 0
+    assert shim.sleqp_hipfact_tr_bind(ctl, handle) == 0, shim.sleqp_error_msg()
+    H = None
+    if not matrix_free:
+        H = _push_matrix(shim, HL)
+        assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0, shim.sleqp_error_msg()
+        assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0  # same pattern: values-only path
     grad = _vec(shim, n, np.arange(n), g)
     mult = _vec(shim, m, [], [])
     step = C.POINTER(SleqpVecC)()
@@ -232,16 +300,166 @@ def test_tr_solver_shim_against_oracle(shim, radius):
     assert shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual)) == 0, \
         shim.sleqp_error_msg()
     got = _dense(step)
-    assert rel_err(got, want) <= 1e-8
+    assert rel_err(got, want) <= (1e-8 if radius < 100 else 1e-6)
     assert np.linalg.norm(got) <= radius * (1 + 1e-10)
+    assert (len(calls) > 0) == matrix_free
     lo, hi = C.c_double(), C.c_double()
     assert shim.sleqp_tr_solver_current_rayleigh(tr, C.byref(lo), C.byref(hi)) == 0
-
     for v in (grad, mult, step):
         shim.sleqp_vec_free(C.byref(v))
-    shim.sleqp_mat_release(C.byref(H))
-    assert shim.sleqp_tr_solver_release(C.byref(tr)) == 0 and not tr
+    if H:
+        shim.sleqp_mat_release(C.byref(H))
+    # the augmented Jacobian may go first: the solver holds its own reference to the factorisation
     assert shim.sleqp_aug_jac_release(C.byref(aug)) == 0
+    assert shim.sleqp_tr_solver_release(C.byref(tr)) == 0 and not tr
     shim.sleqp_iterate_release(C.byref(iterate))
     shim.sleqp_problem_release(C.byref(problem))
     shim.sleqp_settings_release(C.byref(settings))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["convex_interior", "convex_boundary", "indefinite", "hard_case"])
+def test_tr_solver_shim_lanczos_matrix_free(shim, hipfact_lib, case):
+    """TR_SOLVER = TRLIB / AUTO: the generalised Lanczos method with the matrix-free Hessian.  Unlike
+    Steihaug it continues on the boundary and through negative curvature, so run to convergence it must
+    reach the exact solution of the projected trust-region problem (dense eigen-solve in the null space);
+    in the convex interior case it must also agree with the oracle's projected CG."""
+    import scipy.sparse as sp
+
+    import oracle
+    from sleqp_amd import synth
+
+    n, m = 70, 25
+    J = synth.uniform_jacobian(n, m, 4, 11)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.1, 11)
+    rng = np.random.default_rng(8)
+    B = sp.random(n, n, density=0.08, random_state=5)
+    if case.startswith("convex"):
+        Hm = (B @ B.T + 0.5 * sp.eye(n)).toarray()
+        radius = 1e3 if case == "convex_interior" else 0.4
+    else:
+        Hm = (B + B.T).toarray() + np.diag(np.linspace(-2.0, 3.0, n))
+        radius = 1.5
+    g = rng.standard_normal(n)
+    A_W = sp.vstack([sp.eye(n, format="csr")[np.nonzero(vi >= 0)[0]], J.tocsr()]).tocsr()
+    if case == "hard_case":
+        # gradient orthogonal to the leftmost eigenvector of the reduced Hessian
+        import scipy.linalg as sla
+
+        Z = sla.null_space(A_W.toarray())
+        lam, V = np.linalg.eigh(Z.T @ Hm @ Z)
+        gr = Z.T @ g
+        gr -= V[:, 0] * (V[:, 0] @ gr)
+        g = Z @ gr
+        radius = 10.0
+    want, mu = _exact_tr_step(A_W, Hm, g, radius)
+    settings, problem, iterate, aug, handle = _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver=3, stat_tol=1e-9,
+                                                        max_iter=n)
+
+    def hess_prod(direction, duals, product, _):
+        d = np.ctypeslib.as_array(direction, shape=(n,))
+        np.ctypeslib.as_array(product, shape=(n,))[:] = Hm @ d
+        return 0
+
+    cb = HESS_CB(hess_prod)
+    shim.sleqp_problem_set_hess_prod_mini(problem, cb, None)
+    tr, ctl = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_hipfact_tr_solver_create(C.byref(tr), C.byref(ctl), problem, settings) == 0
+    assert shim.sleqp_hipfact_tr_bind(ctl, handle) == 0, shim.sleqp_error_msg()
+    grad = _vec(shim, n, np.arange(n), g)
+    mult = _vec(shim, m, [], [])
+    step = C.POINTER(SleqpVecC)()
+    assert shim.sleqp_vec_create_empty(C.byref(step), n) == 0
+    dual = C.c_double()
+    assert shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual)) == 0, \
+        shim.sleqp_error_msg()
+    got = _dense(step)
+
+    def model(s):
+        return g @ s + 0.5 * s @ (Hm @ s)
+
+    assert np.abs(A_W @ got).max() <= 1e-9 * max(1.0, np.abs(got).max()) * abs(A_W).sum(axis=1).max()
+    assert np.linalg.norm(got) <= radius * (1 + 1e-9)
+    # same model value as the exact solution (the hard case has a whole circle of minimisers)
+    assert model(got) <= model(want) + 1e-7 * max(1.0, abs(model(want)))
+    if case != "hard_case":
+        assert rel_err(got, want) <= 1e-6
+        assert abs(dual.value - mu) <= 1e-6 * max(1.0, mu)
+    if case == "convex_interior":
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        HL = sp.tril(sp.csc_matrix(Hm), format="csc")
+        HL.sort_indices()
+        cg, _ = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius,
+                                                          stat_tol=1e-5)
+        assert rel_err(got, cg) <= 1e-6
+    for v in (grad, mult, step):
+        shim.sleqp_vec_free(C.byref(v))
+    assert shim.sleqp_tr_solver_release(C.byref(tr)) == 0 and not tr
+    _tr_teardown(shim, settings, problem, iterate, aug)
+
+
+@pytest.mark.gpu
+def test_aug_jac_shim_skips_unchanged_working_set_for_linear_constraints(shim, hipfact_lib):
+    """standard_aug_jac.c:247-259: no new factorisation when the constraints are linear and the working set
+    is the one factorised last; a changed working set (or nonlinear constraints) factorises again - as a
+    numeric refactorisation of the cached superset plan."""
+    from sleqp_amd import synth
+
+    n, m = 200, 80
+    J = synth.banded_jacobian(n, m, 6, 40, 2)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.05, 2)
+
+    def info(handle, name):
+        v = C.c_double()
+        assert hipfact_lib.hipfact_get_info(handle, name.encode(), C.byref(v)) == 0
+        return v.value
+
+    for linear in (True, False):
+        settings, problem, iterate, aug, handle = _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver=3, linear=linear)
+        assert info(handle, "num_factor") == 1
+        assert shim.sleqp_aug_jac_set_iterate(aug, iterate) == 0
+        assert info(handle, "num_factor") == (1 if linear else 2)
+        ws = C.c_void_p(shim.sleqp_iterate_working_set(iterate))
+        assert shim.sleqp_working_set_reset(ws) == 0
+        for i in range(m - 3):
+            assert shim.sleqp_working_set_add_cons(ws, i, 1) == 0
+        assert shim.sleqp_aug_jac_set_iterate(aug, iterate) == 0
+        assert info(handle, "num_factor") == (2 if linear else 3)
+        assert info(handle, "analyses") == 1  # the working set changed, the plan did not
+        _tr_teardown(shim, settings, problem, iterate, aug)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/main"), reason="reference tree not present")
+def test_shim_compiles_against_the_reference_headers(tmp_path):
+    """Boundary hygiene: the three shim files, WITHOUT HIPFACT_STANDALONE, type-check against the real
+    headers of chrhansk/sleqp (gcc -fsyntax-only).  The two CMake-generated headers the sources include
+    (sleqp/defs.h from defs.h.in, sleqp/export.h) are the only stand-ins, and they only hold macros."""
+    inc = tmp_path / "sleqp"
+    inc.mkdir()
+    # what CMake would configure from src/main/defs.h.in for -DSLEQP_FACT=HIPFACT (macros only)
+    (inc / "defs.h").write_text(
+        "#ifndef SLEQP_DEFS_H\n#define SLEQP_DEFS_H\n#define SLEQP_VERSION \"1.0.2\"\n"
+        "#define SLEQP_HAVE_ATTRIBUTE_WARN_UNUSED_RESULT\n#define SLEQP_HAVE_ATTRIBUTE_FORMAT\n"
+        "#define SLEQP_FORMAT_PRINTF(index, first) __attribute__((__format__(__printf__, index, first)))\n"
+        "#define SLEQP_FACT_NAME \"hipfact\"\n#define SLEQP_FACT_VERSION \"0.2.0\"\n"
+        "#define SLEQP_FACT_HIPFACT_NAME \"hipfact\"\n#define SLEQP_FACT_HIPFACT_VERSION \"0.2.0\"\n#endif\n")
+    (inc / "export.h").write_text("#ifndef SLEQP_EXPORT_H\n#define SLEQP_EXPORT_H\n#define SLEQP_EXPORT\n"
+                                  "#define SLEQP_NO_EXPORT\n#endif\n")
+    ref = "/root/reference/src/main"
+    # public headers are installed as <sleqp/pub_*.h>: mirror that with symlinks (no copies)
+    for name in os.listdir(ref):
+        if name.startswith("pub_") and name.endswith(".h"):
+            os.symlink(os.path.join(ref, name), inc / name)
+    for sub in ("sparse",):
+        (inc / sub).mkdir()
+        for name in os.listdir(os.path.join(ref, sub)):
+            if name.startswith("pub_") and name.endswith(".h"):
+                os.symlink(os.path.join(ref, sub, name), inc / sub / name)
+    for src in ("fact_hipfact.c", "aug_jac_hipfact.c", "tr_hipfact.c"):
+        # the files live in src/main/{fact,aug_jac,tr}/ of a SLEQP checkout and include their neighbours by
+        # bare name, like fact_lapack.c / standard_aug_jac.c / steihaug_solver.c do
+        cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-I", str(tmp_path), "-I", str(inc), "-I", ref,
+               "-I", os.path.join(ref, "fact"), "-I", os.path.join(ref, "aug_jac"), "-I", os.path.join(ref, "tr"),
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"), os.path.join(ROOT, "shim", src)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
