@@ -6,22 +6,31 @@
 One "step" = one pass of the hot path over one synthetic KKT system whose data
 is already resident in HBM: numeric refactorisation of K (SLEQP_FACT_SET_MATRIX
 with an unchanged sparsity pattern, i.e. the steady state of an SQP run) plus
-one solve K z = b with iterative refinement (SLEQP_FACT_SOLVE).  Workload at
-N=1: BASELINE.json configs[3] (n=1e5, m=5e4, nnz(J)=1e6 `banded`, SURVEY.md
-§8d).  For N>1 every rank factors an independent problem (seed = rank) on its
-own GPU — BASELINE.json configs[4]; there is no data-path collective
-("replicas only"), torch.distributed (RCCL) is used for the
-barrier and the max-over-ranks reduction only.
+one solve K z = b with device-controlled iterative refinement
+(SLEQP_FACT_SOLVE).  Workload at N=1: BASELINE.json configs[3] (n=1e5, m=5e4,
+nnz(J)=1e6 `banded`).  For N>1 every rank factors an independent
+problem (seed = rank) on its own GPU — BASELINE.json configs[4]; there is no
+data-path collective ("replicas only"), torch.distributed (RCCL)
+is used for the barrier and the max-over-ranks reduction only.  `--gpus N`
+without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself:
+N fresh child processes, spawned before this process touches a GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task description) carrying
 `roofline` (dominant kernel, HIP-event timed on the handle's own stream) and
-`cpu_baseline` (the oracle's simplicial sparse LDL^T on the host, rank 0, N=1).
+`cpu_baseline` (the oracle's simplicial sparse LDL^T on the host, rank 0, N=1),
+plus what an unmodified SLEQP would see through the vtable (`boundary`), the
+real 1 : 100 factor : solve ratio (`sqp_iteration`), the cost of a changed
+working set (`working_set_change`), and the SpMV / solve roofline fractions.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
+PROFILE_TAG = "r2"
 
 
 def make_problem(workload: str, seed: int):
@@ -53,15 +63,25 @@ def make_problem(workload: str, seed: int):
 
 
 def algorithmic_bytes(fact):
-    """SURVEY.md §8(d) figures from the backend's own symbolic analysis."""
+    """SURVEY.md §8(d) figures from the backend's own symbolic analysis.  `nnzL` counts structural
+    entries (column counts, no relaxation zeros); the stored dense panels hold more (`nnzL_stored`)."""
+    saddle = fact.info("saddle")
     nnzK = fact.info("nnzK")
-    nnzL = fact.info("nnzL") + fact.info("n") + (fact.info("nnzK") - fact.info("n") if fact.info("saddle") else 0)
+    leaf = fact.info("n") + (nnzK - fact.info("n")) if saddle else 0  # the x columns: I and A
+    nnzL = fact.info("nnzL_true") + leaf
+    nnzL_stored = fact.info("nnzL") + leaf
     # stored row indices: one list per supernode (+ A's indices in saddle mode)
-    nnz_idx = fact.info("rows_total") + (fact.info("nnzK") if fact.info("saddle") else 0)
+    nnz_idx = fact.info("rows_total") + (nnzK if saddle else 0)
     N = fact.info("N")
     factor = 12 * nnzK + 16 * nnzL + 4 * nnz_idx
     solve = 2 * (8 * nnzL + 4 * nnz_idx) + 8 * N + 3 * 8 * N
-    return factor, solve, nnzL
+    return {"factor": factor, "solve": solve, "nnzL": nnzL, "nnzL_stored": nnzL_stored,
+            "factor_stored": 12 * nnzK + 16 * nnzL_stored + 4 * nnz_idx,
+            "solve_stored": 2 * (8 * nnzL_stored + 4 * nnz_idx) + 32 * N}
+
+
+def spmv_bytes(rows, cols, nnz):
+    return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * cols  # SURVEY.md §8(d)
 
 
 def measured_ceilings(device):
@@ -73,8 +93,10 @@ def measured_ceilings(device):
     a = torch.empty(n, dtype=torch.float64, device=device)
     b = torch.ones(n, dtype=torch.float64, device=device)
     c = torch.ones(n, dtype=torch.float64, device=device)
+
     def triad():
         torch.add(b, c, alpha=3.0, out=a)
+
     for _ in range(3):
         triad()
     torch.cuda.synchronize(device)
@@ -101,61 +123,310 @@ def measured_ceilings(device):
             "note": "torch.add triad on 3 x 1 GiB, torch.matmul fp64 8192^3 (rocBLAS)"}
 
 
-def cpu_baseline(N, cp, ri, vx, b, budget_s=20.0):
-    """Oracle (oracle/kkt_oracle.c) simplicial LDL^T, single thread, x-before-y natural order."""
+def host_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "model": model}
+
+
+def suitesparse_probe():
+    """dlopen probe for the libraries the reference's CPU backends bind."""
+    found = {}
+    for lib in ("libcholmod.so", "libcholmod.so.3", "libcholmod.so.5", "libumfpack.so", "libumfpack.so.5",
+                "libumfpack.so.6", "libspqr.so", "libhsl.so", "libcoinhsl.so", "libdmumps.so"):
+        try:
+            C.CDLL(lib)
+            found[lib] = True
+        except OSError:
+            pass
+    return {"present": sorted(found), "note": "none of CHOLMOD / UMFPACK / HSL / MUMPS can be dlopen'ed on this host"
+            if not found else "present but unused: no headers, baseline stays the port"}
+
+
+def cpu_baseline(N, cp, ri, vx, b, budget_s=12.0):
+    """Oracle (oracle/kkt_oracle.c) simplicial LDL^T on the host cores: one core, all cores (independent
+    instances in threads - the ctypes calls release the GIL; the reference's own concurrency model,
+    thread_test.c:77-110), and scipy's SuperLU as an anchor."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle  # test infrastructure; only the baseline leg uses it
 
-    reps, t_total = 0, 0.0
-    t_factor = t_solve = 0.0
-    while reps < 1 or (t_total < budget_s and reps < 50):
+    def one():
         t0 = time.perf_counter()
         F = oracle.OracleLdl(N, cp, ri, vx)
         t1 = time.perf_counter()
         F.solve(b)
         t2 = time.perf_counter()
-        t_factor += t1 - t0
-        t_solve += t2 - t1
-        t_total += t2 - t0
-        reps += 1
         del F
-    return {
-        "value": reps / t_total,
+        return t1 - t0, t2 - t1
+
+    reps, t_total, t_factor, t_solve = 0, 0.0, 0.0, 0.0
+    while reps < 1 or (t_total < budget_s / 2 and reps < 30):
+        f, s = one()
+        t_factor += f
+        t_solve += s
+        t_total += f + s
+        reps += 1
+    single = reps / t_total
+    out = {
+        "value": single,
         "unit": "factor+solve/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{reps} x (numeric+symbolic simplicial LDL^T + 1 solve) of the same K on 1 host core, "
+        "sample": f"{reps} x (symbolic + numeric simplicial LDL^T + 1 solve) of the same K on 1 host core, "
                   f"factor {t_factor / reps * 1e3:.1f} ms, solve {t_solve / reps * 1e3:.2f} ms",
+        "host": host_description(),
+        "suitesparse": suitesparse_probe(),
     }
+    # all cores: one independent instance per core
+    cores = len(os.sched_getaffinity(0))
+    if cores > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        per = max(1, int(budget_s / 2 / max(t_total / reps, 1e-3)))
+        per = min(per, 4)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda _: [one() for _ in range(per)], range(cores)))
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": cores * per / dt, "unit": "factor+solve/s", "cores": cores,
+                            "sample": f"{cores} threads x {per} x the same unit, independent instances"}
+    # scipy SuperLU anchor (SURVEY.md §6 probe: 3.94 s factor / 33.5 ms solve in the survey container)
+    try:
+        import scipy.sparse.linalg as spla
+
+        from sleqp_amd import synth
+
+        K = synth.kkt_full_matrix(N, cp, ri, vx).tocsc()
+        t0 = time.perf_counter()
+        lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options={"SymmetricMode": True})
+        t1 = time.perf_counter()
+        lu.solve(b)
+        t2 = time.perf_counter()
+        out["scipy_splu"] = {"factor_s": t1 - t0, "solve_s": t2 - t1, "value": 1.0 / (t2 - t0),
+                             "unit": "factor+solve/s", "cores": 1, "nnz_LU": int(lu.L.nnz + lu.U.nnz)}
+    except Exception as e:  # noqa: BLE001
+        out["scipy_splu"] = {"error": str(e)[:200]}
+    return out
+
+
+def kernels_sha():
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "hipfact.hip"):
+        h.update(open(os.path.join(ROOT, "sleqp_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(kernel_name):
+    """HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE).  Only valid for the kernel sources it was measured on:
+    the file records their hash, a mismatch yields null instead of a stale number."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None, "no profiles/%s_pmc_traffic.json" % PROFILE_TAG
+    if pmc.get("_kernels_sha16") != kernels_sha():
+        return None, "profiles/%s_pmc_traffic.json was measured on other kernel sources" % PROFILE_TAG
+    rec = pmc.get(kernel_name)
+    if not rec:
+        return None, "kernel not in the PMC file"
+    return rec["fetch_bytes_per_launch_x2"] + rec["write_bytes_per_launch"], \
+        "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernels sha %s" % pmc["_kernels_sha16"]
+
+
+def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
+    """What an unmodified SLEQP sees: the SleqpFact vtable unit of SURVEY.md §8(d) through the C shim
+    (shim/fact_hipfact.c): sleqp_fact_set_matrix(host K) + sleqp_fact_solve(sparse rhs) +
+    sleqp_fact_solution(0, n), host memory in, host memory out."""
+    so = os.path.join(ROOT, "shim", "libsleqp_hipfact_standalone.so")
+    if not os.path.exists(so):
+        return {"error": "shim not built"}
+    shim = C.CDLL(so)
+    shim.sleqp_error_msg.restype = C.c_char_p
+    n = J.shape[1]
+
+    class SleqpVecC(C.Structure):  # sparse/pub_vec.h:16-25
+        _fields_ = [("data", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_int)), ("dim", C.c_int),
+                    ("nnz", C.c_int), ("nnz_max", C.c_int)]
+
+    os.environ["SLEQP_HIP_DEVICE"] = str(local_rank)
+    settings, fact, K = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    if shim.sleqp_fact_create_default(C.byref(fact), settings) != 0:
+        return {"error": shim.sleqp_error_msg().decode()}
+    assert shim.sleqp_mat_create(C.byref(K), N, N, int(cp[N])) == 0
+    cpi = np.ascontiguousarray(cp, dtype=np.int32)
+    rii = np.ascontiguousarray(ri, dtype=np.int32)
+    vxx = np.ascontiguousarray(vx, dtype=np.float64)
+    assert shim.sleqp_mat_set_arrays_mini(K, cpi.ctypes.data_as(C.c_void_p), rii.ctypes.data_as(C.c_void_p),
+                                          vxx.ctypes.data_as(C.c_void_p), int(cp[N])) == 0
+    rhs = C.POINTER(SleqpVecC)()
+    sol = C.POINTER(SleqpVecC)()
+    assert shim.sleqp_vec_create(C.byref(rhs), N, N) == 0
+    assert shim.sleqp_vec_create(C.byref(sol), n, n) == 0
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    assert shim.sleqp_vec_set_from_raw(rhs, bb.ctypes.data_as(C.c_void_p), N, C.c_double(0.0)) == 0
+    zero_eps = C.c_double(1e-20)
+
+    def unit():
+        assert shim.sleqp_fact_set_matrix(fact, K) == 0, shim.sleqp_error_msg()
+        assert shim.sleqp_fact_solve(fact, rhs) == 0, shim.sleqp_error_msg()
+        assert shim.sleqp_fact_solution(fact, sol, 0, n, zero_eps) == 0, shim.sleqp_error_msg()
+
+    t0 = time.perf_counter()
+    unit()  # cold: analysis + uploads + graph capture
+    t_cold = time.perf_counter() - t0
+    for _ in range(3):
+        unit()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        unit()
+    t_unit = (time.perf_counter() - t0) / steps
+
+    def solve_only():
+        assert shim.sleqp_fact_solve(fact, rhs) == 0
+        assert shim.sleqp_fact_solution(fact, sol, 0, n, zero_eps) == 0
+
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solve_only()
+    t_solve = (time.perf_counter() - t0) / steps
+    nnz = int(cp[N])
+    out = {"rate": 1.0 / t_unit, "unit": "factor+solve/s", "ms_per_unit": t_unit * 1e3,
+           "cold_first_call_s": t_cold, "solve_plus_solution_ms": t_solve * 1e3,
+           "pcie_bytes_per_unit": {"up_set_matrix": 8 * nnz, "up_rhs": 12 * N, "down_solution": 8 * n},
+           "note": "through shim/fact_hipfact.c (the five SleqpFact callbacks): pattern compare + hash on the host, "
+                   "values through pinned staging, zero-pivot check (D2H + sync), sparse rhs upload + scatter, "
+                   "solve, refinement verdict, solution(0, n) D2H and sleqp_vec_set_from_raw on the host"}
+    shim.sleqp_vec_free(C.byref(rhs))
+    shim.sleqp_vec_free(C.byref(sol))
+    shim.sleqp_mat_release(C.byref(K))
+    shim.sleqp_fact_release(C.byref(fact))
+    shim.sleqp_settings_release(C.byref(settings))
+    return out
+
+
+def working_set_change_bench(J, local_rank, steps=12):
+    """A new working set every step: +-1 % of the constraint rows enter / leave, bounds
+    become active.  (a) device assembly (hipfact_assemble_kkt, the AugJac boundary): the superset plan is
+    reused, the change costs an upload of J's values and the maps + one numeric refactorisation;
+    (b) the plain SleqpFact boundary sees a new pattern of K each time: plan LRU hit or full analysis."""
+    from sleqp_amd import synth
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    m, n = J.shape
+    rng = np.random.default_rng(5)
+    Jm = SleqpMat.from_scipy(J)
+    sets = []
+    for it in range(steps):
+        ci = np.full(m, -1, dtype=np.int32)
+        drop = rng.choice(m, m // 100, replace=False) if it else np.zeros(0, dtype=int)
+        keep = np.ones(m, dtype=bool)
+        keep[drop] = False
+        vi = np.full(n, -1, dtype=np.int32)
+        av = np.sort(rng.choice(n, (n // 1000) * (it % 3), replace=False)) if it % 3 else np.zeros(0, dtype=int)
+        vi[av] = np.arange(av.size)
+        ci[keep] = av.size + np.arange(int(keep.sum()))
+        sets.append((vi, ci, int(av.size + keep.sum())))
+    fact = HipFact(device=local_rank)
+    t0 = time.perf_counter()
+    fact.assemble_kkt(Jm, *sets[0], want_arrays=False)
+    t_first = time.perf_counter() - t0
+    times = []
+    for vi, ci, W in sets[1:]:
+        t0 = time.perf_counter()
+        fact.assemble_kkt(Jm, vi, ci, W, want_arrays=False)
+        times.append(time.perf_counter() - t0)
+    out = {"device_assembly": {"first_call_s": t_first, "change_ms_median": float(np.median(times)) * 1e3,
+                               "change_ms_max": float(np.max(times)) * 1e3, "analyses": int(fact.info("analyses")),
+                               "rate": 1.0 / float(np.median(times)),
+                               "note": "+-1 % of the rows and up to 0.2 % of the bounds change every call; host J in "
+                                       "(values re-uploaded, pattern hashed), superset plan reused"}}
+    fact.free()
+    # plain boundary: K's pattern changes -> analysis (first visit) or LRU hit (revisit)
+    fact = HipFact(device=local_rank)
+    mats = []
+    for vi, ci, W in sets[:3]:
+        N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+        mats.append(SleqpMat(N, N, cp, ri, vx))
+    first, again = [], []
+    for K in mats:
+        t0 = time.perf_counter()
+        fact.set_matrix(K)
+        first.append(time.perf_counter() - t0)
+    for K in mats:
+        t0 = time.perf_counter()
+        fact.set_matrix(K)
+        again.append(time.perf_counter() - t0)
+    out["fact_vtable"] = {"new_pattern_s": float(np.median(first)), "revisited_pattern_ms": float(np.median(again)) * 1e3,
+                          "analysis_s": fact.info("analysis_s"), "plan_swaps": int(fact.info("plan_swaps")),
+                          "note": "hipfact_set_matrix with K of a changed working set: full analysis on the first "
+                                  "visit of a pattern, plan LRU (analysis, device image, graphs) on a revisit"}
+    fact.free()
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, started before this
+    process has made any GPU call; rank 0's JSON line is relayed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    # ONE JSON line (a gloo fallback on a box with fewer GPUs than ranks chats on stdout)
+    sys.stdout.write("".join(line + "\n" for line in out.splitlines() if line.startswith("{")))
+    sys.stdout.flush()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="banded_n1e5_m5e4")
     ap.add_argument("--refine", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the STREAM / DGEMM ceiling microbenchmarks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the boundary / working-set / SQP-ratio measurements")
     ap.add_argument("--solves-per-factor", type=int, default=1)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
 
     import torch
 
     from sleqp_amd.replicas import Replicas
 
     rep = Replicas()
-    rank, local_rank, world, dist = rep.rank, rep.local_rank, rep.world, rep.dist
+    rank, local_rank, world = rep.rank, rep.local_rank, rep.world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hipfact backend has no CPU path)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from sleqp_amd.fact import HipFact
+    from sleqp_amd.fact import HipFact, SpMat
     from sleqp_amd.sparse import SleqpMat
 
     J, N, cp, ri, vx, b = make_problem(args.workload, seed=rep.problem_seed())
+    n, m = J.shape[1], J.shape[0]
     fact = HipFact(device=local_rank, refine_steps=args.refine)
     t0 = time.perf_counter()
     fact.set_matrix(SleqpMat(N, N, cp, ri, vx))  # cold call: analysis + upload + first factorisation
@@ -166,9 +437,9 @@ def main():
     d_sol = torch.empty_like(d_rhs)
     torch.cuda.synchronize()
 
-    def step():
+    def step(spf=args.solves_per_factor):
         fact.refactor_device(d_vals.data_ptr())
-        for _ in range(args.solves_per_factor):
+        for _ in range(spf):
             fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
 
     def barrier():
@@ -187,6 +458,8 @@ def main():
     t_local = time.perf_counter() - t0
     rep.barrier()
     t_max = rep.max_over_ranks(t_local)
+    per_rank = rep.gather(t_local)
+    fact.check()  # singular / stalled / timed-out work surfaces here (the timed region is asynchronous)
 
     # correctness of what was timed (scaled residual of the last solve)
     from sleqp_amd import synth
@@ -195,12 +468,23 @@ def main():
     z = d_sol.cpu().numpy()
     resid = float(np.abs(K @ z - b).max() / (abs(K).sum(axis=1).max() * np.abs(z).max() + np.abs(b).max()))
 
+    # spread: the same step in 10 chunks (each chunk synchronised once)
+    chunk = max(2, args.steps // 10)
+    chunks = []
+    for _ in range(10):
+        fact.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(chunk):
+            step()
+        fact.synchronize()
+        chunks.append((time.perf_counter() - t0) / chunk * 1e3)
+
     # ---- per-kernel-class timing with HIP events on the handle's stream
     fact.set_option("profile", -1)
     fact.set_option("profile", 1)
     prof_steps = max(3, min(args.steps, 10))
     for _ in range(prof_steps):
-        step()
+        step(1)
     fact.synchronize()
     prof = {}
     for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "factorT", "fwd", "bwd", "rhs",
@@ -212,60 +496,96 @@ def main():
     fact.set_option("profile", 0)
 
     # ---- solve-only rate (the real ratio is ~1 factor : 100 solves, trlib_solver.c:768-776)
-    nsolve = 50
+    nsolve = 100
     fact.synchronize()
-    r0 = fact.info("num_refined")
     t0 = time.perf_counter()
     for _ in range(nsolve):
         fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
     fact.synchronize()
     t_solve = (time.perf_counter() - t0) / nsolve
-    # passes over the factor per solve: 1 + fraction of solves whose residual asked for a correction pass
-    passes = 1.0 + (fact.info("num_refined") - r0) / nsolve * max(args.refine, 0)
+    fact.check()
+    passes = 1.0 + fact.info("last_iters")
 
-    # ---- device-resident projected CG (tr/steihaug_solver.c loop): 20 iterations,
-    # Hessian = symmetric banded SPD matrix, half-bandwidth 5 (§8d), every CG vector resident in HBM
-    eqp = None
-    if args.workload.startswith("banded") and rank == 0:
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- one SQP iteration's linear algebra at the real ratio: 1 factorisation + 100 solves
+        fact.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(100)
+        fact.synchronize()
+        t_sqp = (time.perf_counter() - t0) / reps
+        extras["sqp_iteration"] = {"ms": t_sqp * 1e3, "solves_per_factor": 100, "iterations_per_s": 1.0 / t_sqp,
+                                   "solve_share": 100 * t_solve / t_sqp}
+        # ---- SpMV: J x, J^T y (newton.c:377, working_step.c:341, direction.c:66) and the symmetric Hessian product
         import scipy.sparse as sp
 
-        from sleqp_amd.fact import SpMat
-
-        n = J.shape[1]
         rngh = np.random.default_rng(7)
         diags = [rngh.standard_normal(n - k) * 0.1 for k in range(1, 6)]
         Hl = sp.diags([np.full(n, 2.0)] + diags, [0, -1, -2, -3, -4, -5], format="csc")
         Hl.sort_indices()
-        H = SpMat(fact, SleqpMat(n, n, Hl.indptr, Hl.indices, Hl.data))
+        Jd = SpMat(fact, SleqpMat.from_scipy(J))
+        Hd = SpMat(fact, SleqpMat(n, n, Hl.indptr, Hl.indices, Hl.data))
+        xs = torch.randn(max(n, m), dtype=torch.float64, device=dev)
+        ys = torch.empty(max(n, m), dtype=torch.float64, device=dev)
+        spmv = {}
+        for name, M, trans, (r, c, nz) in (("J_x", Jd, 0, (m, n, J.nnz)), ("JT_y", Jd, 1, (n, m, J.nnz)),
+                                           ("H_sym_x", Hd, 2, (n, n, 2 * Hl.nnz - n))):
+            for _ in range(5):
+                M.mult_device(trans, xs.data_ptr(), ys.data_ptr())
+            fact.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                M.mult_device(trans, xs.data_ptr(), ys.data_ptr())
+            fact.synchronize()
+            dt = (time.perf_counter() - t0) / 200
+            by = spmv_bytes(r, c, nz if trans != 2 else Hl.nnz)
+            spmv[name] = {"us": dt * 1e6, "algorithmic_GBps": by / dt / 1e9, "frac_of_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS}
+        extras["spmv"] = spmv
+        # ---- device-resident Krylov loops, 20 iterations each
         grad = rngh.standard_normal(n)
-        fact.steihaug(H, grad, 1e6, stat_tol=1e-30, max_iter=3)  # warm-up (graph capture)
+        fact.steihaug(Hd, grad, 1e6, stat_tol=1e-30, max_iter=3)  # warm-up (graph capture)
         t0 = time.perf_counter()
-        _, _, its = fact.steihaug(H, grad, 1e6, stat_tol=1e-30, max_iter=20)
+        _, _, its = fact.steihaug(Hd, grad, 1e6, stat_tol=1e-30, max_iter=20)
         t_cg = time.perf_counter() - t0
-        eqp = {"iterations": its, "ms_total": t_cg * 1e3, "ms_per_iteration": t_cg * 1e3 / max(its, 1),
-               "note": "1 projection (KKT solve) + 1 symmetric Hessian SpMV + 3 reductions per iteration, "
-                       "host sees 3 scalars per iteration"}
+        extras["eqp_cg_device"] = {"iterations": its, "ms_per_iteration": t_cg * 1e3 / max(its, 1),
+                                   "note": "explicit Hessian in HBM: 1 projection + 1 symmetric SpMV + 3 reductions per "
+                                           "iteration, host sees 3 scalars"}
+        Hs = (Hl + Hl.T - sp.diags(Hl.diagonal())).tocsr()
+        _, _, its = fact.tr_solve(lambda d: Hs @ d, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
+        t0 = time.perf_counter()
+        _, _, its = fact.tr_solve(lambda d: Hs @ d, grad, 1e6, method=1, stat_tol=1e-30, max_iter=20)
+        t_lz = time.perf_counter() - t0
+        extras["eqp_lanczos_matrix_free"] = {"iterations": its, "ms_per_iteration": t_lz * 1e3 / max(its, 1),
+                                             "note": "GLTR, Hessian product on the host (scipy CSR) through the callback: "
+                                                     "one n-vector down + one up per iteration"}
+        Jd.free()
+        Hd.free()
 
     if rank == 0:
-        fbytes, sbytes, nnzL = algorithmic_bytes(fact)
+        ab = algorithmic_bytes(fact)
+        fbytes, sbytes, nnzL = ab["factor"], ab["solve"], ab["nnzL"]
         dom = max(prof, key=lambda k: prof[k]["ms_per_step"]) if prof else "factor"
         kernel_names = {"factor": "k_factor_level", "factorA": "k_front_assemble", "factorB": "k_front_pivot",
                         "factorC": "k_front_panel", "factorD": "k_front_schur", "factorT": "k_factor_top",
                         "fwd": "k_fwd_top" if fact.info("top_level") == 0 else "k_fwd_level",
                         "bwd": "k_bwd_top" if fact.info("top_level") == 0 else "k_bwd_level", "mvals": "k_mvals_prod",
-                        "memset": "hipMemsetAsync(L arena)"}
+                        "gather": "k_row_scale", "memset": "hipMemsetAsync(L arena)"}
         launches = prof[dom]["launches_per_step"]
         # algorithmic bytes attributable to the dominant kernel, per launch:
         #   factor kernels: write L once + read it once for the updates (16 B/entry) + row indices (4 B) of the
-        #   fronts that kernel family processes; the split phases A-D share their fronts' bytes.
+        #   fronts that kernel family processes; the split phases A-D share their fronts' bytes.  The stored
+        #   panel entries are scaled down to structural entries (nnzL_true / nnzL).
+        true_frac = fact.info("nnzL_true") / max(fact.info("nnzL"), 1.0)
         if dom == "factor":
-            step_bytes = 16 * fact.info("ent_fused") + 4 * fact.info("rows_fused")
+            step_bytes = 16 * fact.info("ent_fused") * true_frac + 4 * fact.info("rows_fused")
         elif dom in ("factorA", "factorB", "factorC", "factorD", "factorT"):
             # the per-level kernels and the single-launch top-of-tree kernel share the fronts' bytes by time
             fam = sum(prof[k]["ms_per_step"] for k in ("factorA", "factorB", "factorC", "factorD", "factorT") if k in prof)
-            step_bytes = (16 * fact.info("ent_split") + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
+            step_bytes = (16 * fact.info("ent_split") * true_frac + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
         elif dom in ("fwd", "bwd"):
-            step_bytes = (sbytes / 2) * prof[dom]["launches_per_step"] / max(fact.info("nlevels"), 1)
+            step_bytes = sbytes / 2
         elif dom == "mvals":
             step_bytes = 12 * fact.info("nnzK") + 8 * fact.info("nnzM")
         else:
@@ -275,18 +595,11 @@ def main():
         achieved = bytes_per_launch / avg_s / 1e9
         factor_ms = sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor", "factorA", "factorB",
                                                           "factorC", "factorD", "factorT") if k in prof)
-        # HBM traffic of the dominant kernel from the PMC counters (separate rocprofv3 --pmc passes of this
-        # same command, profiles/r1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            rec = pmc.get(kernel_names.get(dom, dom))
-            if rec and args.workload == "banded_n1e5_m5e4":
-                traffic = rec["fetch_bytes_per_launch_x2"] + rec["write_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
+        traffic, traffic_note = (None, "workload other than the profiled one")
+        if args.workload == "banded_n1e5_m5e4":
+            traffic, traffic_note = load_traffic(kernel_names.get(dom, dom))
         out = {
-            "metric": "KKT factor+solve/sec (numeric refactor + 1 solve with residual-checked refinement, inputs resident in HBM)",
+            "metric": "KKT factor+solve/sec (numeric refactor + 1 solve with device-controlled refinement, inputs resident in HBM)",
             "value": rep.aggregate_rate(args.steps, t_max),
             "unit": "factor+solve/s",
             "n_gpus": world,
@@ -300,25 +613,34 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "n": int(fact.info("n")), "m": int(fact.info("m")), "N": N,
                        "nnz_J": int(J.nnz), "nnz_tril_K": int(fact.info("nnzK")), "nnz_L": int(nnzL),
+                       "nnz_L_stored": int(ab["nnzL_stored"]),
                        "supernodes": int(fact.info("nsuper")), "etree_levels": int(fact.info("nlevels")),
-                       "refine_steps": args.refine, "refine_adaptive": bool(fact.info("refine_adaptive")),
-                       "refine_tol": 5e-13, "hip_graphs": int(fact.info("num_graphs")),
+                       "refine_steps": args.refine, "refine_target": fact.info("refine_tol"),
+                       "equilibrate": bool(fact.info("equilibrate")), "hip_graphs": int(fact.info("num_graphs")),
                        "solves_per_factor": args.solves_per_factor,
                        "parallelism": f"replicas{world}" if world > 1 else "single"},
+            "per_rank_ms_per_step": {"min": min(per_rank) / args.steps * 1e3, "max": max(per_rank) / args.steps * 1e3,
+                                     "all": [t / args.steps * 1e3 for t in per_rank]},
+            "spread_ms_per_step": {"chunks": 10, "steps_per_chunk": chunk, "min": min(chunks), "median": float(np.median(chunks)),
+                                   "max": max(chunks)},
             "roofline": {"bound": "hbm", "kernel": kernel_names.get(dom, dom), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_basis": "structural nnz(L) (column counts); stored dense panels: x%.3f" % (1.0 / true_frac),
                          "avg_launch_us": prof[dom]["avg_launch_us"]},
             "kernels": prof,
             "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3,
-                           "passes_per_solve": passes, "algorithmic_GBps": sbytes * passes / t_solve / 1e9},
+                           "passes_per_solve": passes, "algorithmic_GBps": sbytes * passes / t_solve / 1e9,
+                           "frac_of_hbm_peak": sbytes * passes / t_solve / 1e9 / HBM_PEAK_GBS,
+                           "last_omega": fact.info("last_omega"), "kappa_est": fact.info("kappa_est")},
             "factor_only_ms": factor_ms,
             "factor_family_GBps": fbytes / (factor_ms * 1e-3) / 1e9,
-            "eqp_cg_device": eqp,
             "cold_set_matrix_s": t_cold,
             "analysis_s": fact.info("analysis_s"),
             "scaled_residual": resid,
         }
+        out.update(extras)
         # dense-front workloads (config 3): the Schur kernel is bound by the fp64 matrix cores, not by HBM
         flops = fact.info("flops")
         if dom == "factorD" and flops / max(fbytes, 1.0) > MFMA_F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
@@ -327,6 +649,11 @@ def main():
                                "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                                "flops_per_step": flops, "avg_launch_us": prof[dom]["avg_launch_us"],
                                "note": "all factor flops attributed to the Schur kernel (upper bound)"}
+        fact.free()
+        if world == 1 and not args.no_extras:
+            out["boundary"] = boundary_bench(J, N, cp, ri, vx, b, 30, local_rank)
+            if args.workload.startswith("banded"):
+                out["working_set_change"] = working_set_change_bench(J, local_rank)
         if world == 1 and not args.no_ceilings:
             out["measured_ceilings"] = measured_ceilings(f"cuda:{local_rank}")
         if world == 1 and not args.no_cpu_baseline:

@@ -252,6 +252,20 @@ sleqp_mat_reserve(SleqpMat* m, int nnz)
 }
 
 SLEQP_RETCODE
+sleqp_mat_set_arrays_mini(SleqpMat* m, const int* cols, const int* rows, const double* data, int nnz)
+{
+  SLEQP_CALL(sleqp_mat_reserve(m, nnz));
+  memcpy(m->cols, cols, (size_t)(m->num_cols + 1) * sizeof(int));
+  if (nnz > 0)
+  {
+    memcpy(m->rows, rows, (size_t)nnz * sizeof(int));
+    memcpy(m->data, data, (size_t)nnz * sizeof(double));
+  }
+  m->nnz = nnz;
+  return SLEQP_OKAY;
+}
+
+SLEQP_RETCODE
 sleqp_mat_resize(SleqpMat* m, int num_rows, int num_cols)
 {
   if (num_cols + 1 > m->cols_cap)

@@ -180,6 +180,9 @@ int*
 sleqp_mat_rows(const SleqpMat* matrix);
 SLEQP_RETCODE
 sleqp_mat_release(SleqpMat** matrix);
+/* harness only: bulk load of CSC arrays (what nnz calls of sleqp_mat_push_col / sleqp_mat_push would build) */
+SLEQP_RETCODE
+sleqp_mat_set_arrays_mini(SleqpMat* matrix, const int* cols, const int* rows, const double* data, int nnz);
 
 /* ---- SleqpFact (fact/fact.h, fact/fact_types.h) ---- */
 typedef struct SleqpFact SleqpFact;

@@ -142,6 +142,34 @@ class HipFact:
                                                      int(max_iter), _ptr(step), C.byref(dual), C.byref(its)))
         return step, dual.value, its.value
 
+    def tr_solve(self, hess, gradient, trust_radius: float, method: int = 1, stat_tol: float = 1e-6,
+                 max_iter: int = 100):
+        """hipfact_tr_solve: method 0 = projected Steihaug CG (tr/steihaug_solver.c), 1 = generalised Lanczos
+        (what trlib runs, tr/trlib_solver.c).  `hess` is an SpMat (explicit lower-triangular Hessian in HBM)
+        or a callable d -> H d on host arrays (the matrix-free SLEQP_FUNC_HESS_PROD).  Returns
+        (step, tr_dual, iterations)."""
+        g = np.ascontiguousarray(gradient, dtype=np.float64)
+        n = g.size
+        step = np.empty_like(g)
+        dual, its = C.c_double(), C.c_int()
+        cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+        if isinstance(hess, SpMat):
+            mat, cb = hess._m, C.cast(None, cb_type)
+        else:
+            def _prod(_user, direction, product):
+                try:
+                    d = np.ctypeslib.as_array(direction, shape=(n,))
+                    np.ctypeslib.as_array(product, shape=(n,))[:] = hess(d)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return -1
+
+            mat, cb = None, cb_type(_prod)
+        self._check(self._lib.hipfact_tr_solve(self._h, int(method), mat, cb, None, _ptr(g), float(trust_radius),
+                                               stat_tol * 1e-2, int(max_iter), _ptr(step), C.byref(dual),
+                                               C.byref(its)))
+        return step, dual.value, its.value
+
     def free(self):
         if self._h:
             self._lib.hipfact_free(C.byref(self._h))

@@ -25,7 +25,12 @@ class Replicas:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # RCCL needs one GPU per rank; with fewer GPUs than ranks (a 1-GPU box exercising the
+                # N-rank launcher) the ranks share devices and synchronise over gloo
+                enough = torch.cuda.is_available() and torch.cuda.device_count() >= self.world
+                backend = "nccl" if enough else "gloo"
+                if torch.cuda.is_available() and not enough:
+                    self.local_rank %= torch.cuda.device_count()
             self.backend = backend
             kwargs = {}
             if backend == "nccl":
@@ -51,6 +56,18 @@ class Replicas:
         t = torch.tensor([value], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(self, value: float) -> list:
+        """Every rank's value, in rank order (per-GPU min / max reporting)."""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+
+        dev = torch.device("cuda", self.local_rank) if self.backend == "nccl" else torch.device("cpu")
+        mine = torch.tensor([value], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [float(p.item()) for p in parts]
 
     def aggregate_rate(self, steps_per_rank: int, t_max: float) -> float:
         """Whole-job throughput: units processed by all ranks / slowest rank's time."""
