@@ -487,8 +487,8 @@ def main():
         step(1)
     fact.synchronize()
     prof = {}
-    for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "factorT", "fwd", "bwd", "rhs",
-                "xupd", "resid", "axpy", "perm"):
+    for cls in ("memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC", "factorD", "factorT", "spanel", "fwd",
+                "bwd", "tree", "rhs", "xupd", "resid", "axpy", "perm"):
         ms, cnt = fact.info(f"prof_{cls}_ms"), fact.info(f"prof_{cls}_count")
         if cnt > 0:
             prof[cls] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps,
@@ -571,7 +571,8 @@ def main():
                         "factorC": "k_front_panel", "factorD": "k_front_schur", "factorT": "k_factor_top",
                         "fwd": "k_fwd_top" if fact.info("top_level") == 0 else "k_fwd_level",
                         "bwd": "k_bwd_top" if fact.info("top_level") == 0 else "k_bwd_level", "mvals": "k_mvals_prod",
-                        "gather": "k_row_scale", "memset": "hipMemsetAsync(L arena)"}
+                        "gather": "k_row_scale", "memset": "hipMemsetAsync(L arena)", "tree": "k_solve_tree",
+                        "spanel": "k_build_solve_panels"}
         launches = prof[dom]["launches_per_step"]
         # algorithmic bytes attributable to the dominant kernel, per launch:
         #   factor kernels: write L once + read it once for the updates (16 B/entry) + row indices (4 B) of the
@@ -586,6 +587,8 @@ def main():
             step_bytes = (16 * fact.info("ent_split") * true_frac + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
         elif dom in ("fwd", "bwd"):
             step_bytes = sbytes / 2
+        elif dom == "tree":
+            step_bytes = sbytes
         elif dom == "mvals":
             step_bytes = 12 * fact.info("nnzK") + 8 * fact.info("nnzM")
         else:
@@ -594,7 +597,7 @@ def main():
         avg_s = prof[dom]["avg_launch_us"] * 1e-6
         achieved = bytes_per_launch / avg_s / 1e9
         factor_ms = sum(prof[k]["ms_per_step"] for k in ("memset", "mvals", "gather", "factor", "factorA", "factorB",
-                                                          "factorC", "factorD", "factorT") if k in prof)
+                                                          "factorC", "factorD", "factorT", "spanel") if k in prof)
         traffic, traffic_note = (None, "workload other than the profiled one")
         if args.workload == "banded_n1e5_m5e4":
             traffic, traffic_note = load_traffic(kernel_names.get(dom, dom))

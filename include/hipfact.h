@@ -265,6 +265,10 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value);
  * "solve_bytes", "factor_bytes", ... */
 int hipfact_get_info(const hipfact_handle* h, const char* name, double* value);
 
+/* Debugging aid (tests, scripts): copies the first `bytes` of a named device buffer of the active plan
+ * state to the host ("L", "SPf", "SPb", "sitems", "y", "xhat", "ysol", "uvec", "dscale"). */
+int hipfact_debug_copy(hipfact_handle* h, const char* name, void* out, size_t bytes);
+
 /* ---- host-only symbolic plan (no GPU needed; used by the tests) ---------- */
 
 typedef struct hipfact_plan hipfact_plan;

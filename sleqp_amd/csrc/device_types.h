@@ -83,6 +83,27 @@ struct TopItem {
   long long poff;            // backward: the front's partial sums (nsl x w) in the scratch buffer
   int c_invoff[MAXCH];       // children's inverse relative indices
 };
+// One front of the fused solve launch (k_solve_tree): everything a workgroup needs in ONE uniform
+// load.  The front's factor is stored twice in "solve panel" form, S = [X; -W] with X = inv(L11)
+// (unit lower) and W = L21 X, so that each sweep is a single product with no dependency between the
+// pivot rows and the update rows (forward: [x^; u] = S f_top + [0; f_below]; backward:
+// x = S^T [D^-1 x^; g]):
+//   forward copy   thread (row i, column class q):   entries S[i, q + Qf e],        e < Ef
+//   backward copy  thread (column k, row class p):   entries S[p + Pb e, k] (rows < w divided by d), e < Eb
+// both laid out thread-major (entry e of thread t at e * threads + t): every load instruction of the
+// workgroup is one contiguous run, and the entries live in registers across the dependency wait.
+struct SolveItem {
+  long long spf, spb;        // offsets of the two copies in the solve-panel arenas
+  long long uoff, rowoff;    // own update vector; row structure (front rows -> pivot indices)
+  int c0, w, r, nchild;
+  int Qf, Ef, Pb, Eb;
+  long long c_uoff[MAXCH];   // children's update vectors
+  int c_invoff[MAXCH];       // children's inverse relative indices (which update row lands on front row i)
+  long long Loff;            // the front's panel (source of the solve panels)
+  int xbegin, xend;          // children beyond the first MAXCH: entries [xbegin, xend) of the overflow lists
+};
+constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
+
 constexpr int WIDE_SLICE_ROWS = 256;
 constexpr int TOP_REL_CAP = 2048;   // ints of children's relative indices staged in LDS
 constexpr int TOP_L21_CAP = 16384;  // doubles of L21 (forward) / inv(L11) (backward) staged in LDS

@@ -104,9 +104,10 @@ struct LevelInfo {
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
-enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FACTOR_A, PC_FACTOR_B, PC_FACTOR_C, PC_FACTOR_D, PC_FACTOR_T, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_COUNT };
+enum ProfClass { PC_MEMSET = 0, PC_MVALS, PC_GATHER, PC_FACTOR, PC_FACTOR_A, PC_FACTOR_B, PC_FACTOR_C, PC_FACTOR_D, PC_FACTOR_T, PC_FWD, PC_BWD, PC_RHS, PC_XUPD, PC_RESID, PC_AXPY, PC_PERM, PC_SPANEL, PC_TREE, PC_COUNT };
 static const char* const kProfNames[PC_COUNT] = {"memset", "mvals", "gather", "factor", "factorA", "factorB", "factorC",
-                                                 "factorD", "factorT", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm"};
+                                                 "factorD", "factorT", "fwd", "bwd", "rhs", "xupd", "resid", "axpy", "perm",
+                                                 "spanel", "tree"};
 
 struct Prof {
   bool on = false;
@@ -201,6 +202,11 @@ struct PlanState {
   DevBuf d_ysol;    // polled copy of the solution of M y = t (single-launch backward sweep)
   DevBuf d_Kval, d_L, d_U, d_uvec, d_y, d_rhs, d_sol, d_res;
   DevBuf d_Ksc, d_Kprod, d_dscale, d_vmap, d_cmap, d_diag_target, d_sidx, d_srow;
+  // fused solve (k_solve_tree): solve panels S = [X; -W] in two thread-major copies, x^ exchange slots
+  bool fused_solve = false;
+  size_t sp_lds = 0;
+  double sp_bytes = 0;
+  DevBuf d_SPf, d_SPb, d_sitems, d_xhat, d_sxuoff, d_sxinvoff, d_epoch;
 
   PlanState() = default;
   PlanState(PlanState&&) = default;
@@ -215,6 +221,7 @@ struct hipfact_handle : PlanState {
   PlanParams prm;
   std::vector<std::unique_ptr<PlanState>> cache;  // inactive plan states, at most plan_cache_max
   int plan_cache_max = 4;
+  bool solve_fused = true;        // one launch for the whole solve tree on the solve panels (when every front qualifies)
   bool assemble_superset = true;  // hipfact_assemble_kkt analyses a superset structure of J instead of K itself
   bool jdev_valid = false;        // pattern of the Jacobian resident in d_jp / d_ji
   unsigned long long jdev_hash = 0;
@@ -799,7 +806,76 @@ static int upload_plan(hipfact_handle* h) {
     HCHECK(h, h->d_flags.ensure(std::max<size_t>((size_t)4 * ns * sizeof(int), 16)));
     HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * ns * sizeof(int), h->stream));
   }
-  if (max_lds > 160 * 1024) {
+  {
+    // fused solve launch: every front as a SolveItem, children before parents (level order)
+    h->fused_solve = false;
+    bool ok = h->solve_fused && ns > 0;
+    for (int s2 = 0; s2 < ns && ok; ++s2) ok = sn[s2].r <= 1024 && sn[s2].w >= 1;
+    if (ok) {
+      std::vector<SolveItem> si;
+      std::vector<long long> xuoff;  // children beyond the first MAXCH of a front
+      std::vector<int> xinvoff;
+      si.reserve(ns);
+      long long spf = 0, spb = 0;
+      int wmax = 1;
+      for (int q = 0; q < ns; ++q) {
+        const int s2 = P.level_sn[q];
+        SolveItem T;
+        memset(&T, 0, sizeof(T));
+        T.c0 = sn[s2].c0;
+        T.w = sn[s2].w;
+        T.r = sn[s2].r;
+        T.uoff = sn[s2].uoff;
+        T.rowoff = sn[s2].rowoff;
+        T.Loff = sn[s2].Loff;
+        const int nch = sn[s2].child_end - sn[s2].child_begin;
+        T.nchild = std::min(nch, MAXCH);
+        T.xbegin = (int)xuoff.size();
+        for (int k = 0; k < nch; ++k) {
+          const int ch = P.child_idx[sn[s2].child_begin + k];
+          if (k < MAXCH) {
+            T.c_uoff[k] = sn[ch].uoff;
+            T.c_invoff[k] = sn[ch].pad1;
+          } else {
+            xuoff.push_back(sn[ch].uoff);
+            xinvoff.push_back(sn[ch].pad1);
+          }
+        }
+        T.xend = (int)xuoff.size();
+        T.Qf = std::max(1, std::min(T.w, 1024 / T.r));
+        T.Ef = (T.w + T.Qf - 1) / T.Qf;
+        T.Pb = std::max(1, std::min(T.r, 1024 / T.w));
+        T.Eb = (T.r + T.Pb - 1) / T.Pb;
+        T.spf = spf;
+        T.spb = spb;
+        spf += ((long long)T.Ef * T.r * T.Qf + 1) & ~1LL;
+        spb += ((long long)T.Eb * T.w * T.Pb + 1) & ~1LL;
+        wmax = std::max(wmax, T.w);
+        si.push_back(T);
+      }
+      {
+        const size_t wp = (size_t)((wmax + 15) & ~15);
+        h->sp_lds = (wp * (wp + 1) + wp + 8 * 16 * 17) * sizeof(double);  // X | 1 / d | one tile per wave
+      }
+      if (h->sp_lds <= 160 * 1024) {
+        if ((rc = upload(h, h->d_sitems, si))) return rc;
+        if ((rc = upload(h, h->d_sxuoff, xuoff))) return rc;
+        if ((rc = upload(h, h->d_sxinvoff, xinvoff))) return rc;
+        HCHECK(h, h->d_SPf.ensure(std::max<size_t>((size_t)spf * sizeof(double), 16)));
+        HCHECK(h, h->d_SPb.ensure(std::max<size_t>((size_t)spb * sizeof(double), 16)));
+        HCHECK(h, hipMemsetAsync(h->d_SPf.p, 0, std::max<size_t>((size_t)spf * sizeof(double), 16), h->stream));
+        HCHECK(h, hipMemsetAsync(h->d_SPb.p, 0, std::max<size_t>((size_t)spb * sizeof(double), 16), h->stream));
+        HCHECK(h, h->d_xhat.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+        HCHECK(h, hipMemsetAsync(h->d_xhat.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), h->stream));
+        HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_solve_panels),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->fused_solve = true;
+        h->sp_bytes = (double)(spf + spb) * sizeof(double);
+      }
+    }
+  }
+  // the LDS-resident solve vectors of the per-level / two-launch kernels only matter when those run
+  if (!h->fused_solve && max_lds > 160 * 1024) {
     h->error = "front too large for LDS-resident solve vectors";
     return HIPFACT_EINTERNAL;
   }
@@ -823,9 +899,11 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_y.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
   // exchanged element by element in the single-launch solve sweeps: every slot starts as the
   // sentinel (all bits set) and is put back by the opposite sweep after use
-  HCHECK(h, h->d_ysol.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
+  HCHECK(h, h->d_ysol.ensure(std::max<size_t>((size_t)2 * P.m * sizeof(double), 16)));  // two copies: the fused launches alternate
   HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), h->stream));
-  HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), h->stream));
+  HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)2 * P.m * sizeof(double), 16), h->stream));
+  HCHECK(h, h->d_epoch.ensure(16));
+  HCHECK(h, hipMemsetAsync(h->d_epoch.p, 0, 16, h->stream));
   const size_t nb = std::max<size_t>((size_t)std::max(P.N, h->N_ext) * sizeof(double), 16);
   HCHECK(h, h->d_rhs.ensure(nb));
   HCHECK(h, h->d_sol.ensure(nb));
@@ -947,6 +1025,9 @@ static int factor_enqueue(hipfact_handle* h) {
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
            fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>());
   }
+  if (h->fused_solve)
+    LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper), dim3(SPB), h->sp_lds, h->d_sitems.as<SolveItem>(),
+           h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;
 }
@@ -975,7 +1056,8 @@ static int reset_dataflow_state(hipfact_handle* h) {
   hipStream_t st = h->stream;
   if (h->d_xarena.p) HCHECK(h, hipMemsetAsync(h->d_xarena.p, 0xFF, h->d_xarena.bytes, st));
   if (h->d_uvec.p) HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), st));
-  if (h->d_ysol.p) HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), st));
+  if (h->d_ysol.p) HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)2 * P.m * sizeof(double), 16), st));
+  if (h->d_xhat.p) HCHECK(h, hipMemsetAsync(h->d_xhat.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), st));
   if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
   HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));
@@ -1033,6 +1115,14 @@ static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
 // every launch into a no-op (correction passes of a solve that has already converged)
 static void solve_m_async(hipfact_handle* h, const int* skip) {
   const Plan& P = h->plan;
+  if (h->fused_solve) {
+    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
+           h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
+           h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
+           h->d_xhat.as<double>(), h->d_uvec.as<double>(), h->d_ysol.as<double>(), P.m, h->d_epoch.as<int>(),
+           h->d_info.as<int>(), skip);
+    return;
+  }
   const int ltop = std::min(h->top_level, P.nlevels);
   for (int l = 0; l < ltop; ++l) {
     const LevelInfo& li = h->levels[l];
@@ -1065,6 +1155,8 @@ static void solve_m_async(hipfact_handle* h, const int* skip) {
 static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool acc, const int* skip) {
   const Plan& P = h->plan;
   if (h->N_ext == 0) return;
+  // fused solve launch: the kernel behind it advances the epoch of its double-buffered exchange slots
+  int* epoch = (h->fused_solve && P.m > 0) ? h->d_epoch.as<int>() : nullptr;
   if (P.saddle) {
     const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
@@ -1074,20 +1166,20 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
     }
     if (acc)
       LAUNCH(PC_XUPD, k_x_saddle<true>, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
-             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip);
+             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip, epoch);
     else
       LAUNCH(PC_XUPD, k_x_saddle<false>, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
-             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip);
+             h->d_Ksc.as<double>(), h->d_Kc_y.as<int>(), h->d_perm.as<int>(), M, h->d_y.as<double>(), b, z, skip, epoch);
   } else {
     LAUNCH(PC_PERM, k_gather_skip, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(), b,
            h->d_y.as<double>(), skip);
     solve_m_async(h, skip);
     if (acc)
       LAUNCH(PC_PERM, k_scatter_acc, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
-             h->d_y.as<double>(), z, skip);
+             h->d_y.as<double>(), z, skip, epoch);
     else
       LAUNCH(PC_PERM, k_scatter, dim3(nblocks(P.m)), dim3(FB), 0, (long long)P.m, h->d_perm.as<int>(),
-             h->d_y.as<double>(), z);
+             h->d_y.as<double>(), z, epoch);
   }
 }
 
@@ -2354,6 +2446,11 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     invalidate_plans(h);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "solve_fused")) {  // 0: the two-launch / per-level solve kernels on the factor panels
+    h->solve_fused = value != 0.0;
+    invalidate_plans(h);
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "assemble_superset")) {
     h->assemble_superset = value != 0.0;
     return HIPFACT_OK;
@@ -2397,6 +2494,29 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   return HIPFACT_EINVAL;
 }
 
+int hipfact_debug_copy(hipfact_handle* h, const char* name, void* out, size_t bytes) {
+  int rc = enter(h);
+  if (rc) return rc;
+  if (!name || !out) return HIPFACT_EINVAL;
+  const DevBuf* b = nullptr;
+  if (!strcmp(name, "L")) b = &h->d_L;
+  else if (!strcmp(name, "SPf")) b = &h->d_SPf;
+  else if (!strcmp(name, "SPb")) b = &h->d_SPb;
+  else if (!strcmp(name, "sitems")) b = &h->d_sitems;
+  else if (!strcmp(name, "y")) b = &h->d_y;
+  else if (!strcmp(name, "xhat")) b = &h->d_xhat;
+  else if (!strcmp(name, "ysol")) b = &h->d_ysol;
+  else if (!strcmp(name, "uvec")) b = &h->d_uvec;
+  else if (!strcmp(name, "dscale")) b = &h->d_dscale;
+  if (!b || !b->p || bytes > b->bytes) {
+    h->error = "hipfact_debug_copy: unknown buffer or size";
+    return HIPFACT_EINVAL;
+  }
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  HCHECK(h, hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost));
+  return HIPFACT_OK;
+}
+
 int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return HIPFACT_EINVAL;
   const Plan& P = h->plan;
@@ -2428,7 +2548,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("fused_solve", h->fused_solve) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

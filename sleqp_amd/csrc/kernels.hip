@@ -215,6 +215,13 @@ __device__ __forceinline__ void post_f64(double* __restrict__ p, double v) {
 __device__ __forceinline__ void sent_f64(double* __restrict__ p) {
   *reinterpret_cast<unsigned long long*>(p) = SOLVE_SENT;
 }
+// Same, for a slot that is posted or polled again inside the SAME launch.  The eight XCDs have an L2
+// each; a plain store may sit there as a dirty line and be written back over a value that another XCD
+// has posted in the meantime with an agent-scope store.  (Resets whose next use is a launch away may
+// stay plain: the end of a kernel writes the L2s back.)
+__device__ __forceinline__ void sent_f64_agent(double* __restrict__ p) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), SOLVE_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct FrontCtx {
   int w, r, u, wp, nbk, lda;
@@ -2491,6 +2498,258 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
 }
 
 // ---------------------------------------------------------------------------
+// The whole elimination tree of a solve in ONE launch (fused forward + backward sweep) on the
+// "solve panels" S = [X; -W], X = inv(L11), W = L21 X.
+//
+// Why another form of the factor.  With L21 itself a front's forward step is two dependent products
+// (x^ = X f_top, then u = f_below - L21 x^) and so is its backward step; every product is a
+// barrier-separated phase of a 1024-thread workgroup, and the tree's critical path pays them level
+// after level.  With W = L21 X both sweeps are ONE product per front:
+//     forward   [x^; u] = [X; -W] f_top + [0; f_below]
+//     backward  x = [X; -W]^T [D^-1 x^; g]          (since X^T L21^T = W^T)
+// The panels are stored twice, thread-major (SolveItem), so that a thread's share of the front sits
+// in registers BEFORE its dependency wait and the product afterwards is a run of register FMAs
+// against a vector in LDS; the only cross-thread step is the sum of Qf (Pb) partials through LDS.
+// 2 x nfronts workgroups: blocks [0, nf) forward, children before parents; blocks [nf, 2 nf)
+// backward, parents before children.  Workgroups are dispatched in index order and only ever wait
+// for lower-indexed ones, so progress needs no co-residency.  Data is its own flag (poll_f64 /
+// post_f64): update vectors (forward), x^ (forward item -> backward item of the same front: this is
+// how the root turns around without a launch boundary), solution copy ysol (backward).  Every
+// polled slot is put back to the sentinel by its consumer's side: uvec and x^ by the backward item
+// of the front (agent-scope stores: other slots of the same cache lines are live in this launch).
+// ysol exists twice and the launches alternate (`epoch`, advanced by the kernel that follows the
+// tree): a backward item may start polling long before the forward item of an ancestor has run,
+// so it must never find the previous solve's value - the copy of the previous launch is put back to
+// the sentinel by the forward items while this launch exchanges through the other one.
+// ---------------------------------------------------------------------------
+constexpr int ST = 1024;  // threads per workgroup
+
+__device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* __restrict__ SPf,
+                                              const long long* __restrict__ xuoff, const int* __restrict__ xinvoff,
+                                              const int* __restrict__ inv, const double* __restrict__ y,
+                                              double* __restrict__ xhat, double* __restrict__ uvec,
+                                              double* __restrict__ ysol, double* lds, int* __restrict__ info) {
+  const int tid = threadIdx.x;
+  const int w = T.w, r = T.r, Q = T.Qf, E = T.Ef;
+  const int TS = r * Q;
+  const bool active = tid < TS;
+  const int i = active ? tid % r : 0, q = active ? tid / r : 0;
+  double* f = lds;          // r
+  double* part = lds + r;   // Q * r <= 1024
+  // the copy of the solution the PREVIOUS launch exchanged through: back to the sentinel
+  if (tid < w) sent_f64(ysol + T.c0 + tid);
+  const double* __restrict__ sp = SPf + T.spf + tid;
+  double pv[SOLVE_PREFETCH];
+#pragma unroll
+  for (int e = 0; e < SOLVE_PREFETCH; ++e) pv[e] = (active && e < E) ? sp[(long long)e * TS] : 0.0;
+  // front row tid: own right-hand side and, per child, which of its update rows lands here
+  double f0 = (tid < w) ? y[T.c0 + tid] : 0.0;
+  int iv[MAXCH];
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < r) ? inv[T.c_invoff[ch] + tid] : -1;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (iv[ch] >= 0) f0 += poll_f64(uvec + T.c_uoff[ch] + iv[ch], info);  // child order: deterministic
+  for (int x = T.xbegin; x < T.xend; ++x) {  // fronts with more than MAXCH children (rare)
+    const int ia = (tid < r) ? inv[xinvoff[x] + tid] : -1;
+    if (ia >= 0) f0 += poll_f64(uvec + xuoff[x] + ia, info);
+  }
+  if (tid < r) f[tid] = f0;
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < SOLVE_PREFETCH; ++e)
+    if (e < E) acc = fma(pv[e], f[min(q + Q * e, w - 1)], acc);  // entries beyond column w - 1 are stored as zeros
+  for (int e = SOLVE_PREFETCH; e < E; ++e)
+    if (active) acc = fma(sp[(long long)e * TS], f[min(q + Q * e, w - 1)], acc);
+  if (active) part[tid] = acc;
+  __syncthreads();
+  if (tid < r) {
+    double s2 = 0.0;
+    for (int qq = 0; qq < Q; ++qq) s2 += part[qq * r + tid];
+    if (tid < w)
+      post_f64(xhat + T.c0 + tid, s2);  // X has a unit diagonal: f[tid] is inside the product
+    else
+      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);
+  }
+}
+
+__device__ __forceinline__ void dev_solve_bwd(const SolveItem& T, const double* __restrict__ SPb,
+                                              const int* __restrict__ rows, double* __restrict__ y,
+                                              double* __restrict__ xhat, double* __restrict__ uvec,
+                                              double* __restrict__ ysol, double* lds, int* __restrict__ info) {
+  const int tid = threadIdx.x;
+  const int w = T.w, r = T.r, P = T.Pb, E = T.Eb;
+  const int TS = w * P;
+  const bool active = tid < TS;
+  const int k = active ? tid % w : 0, p = active ? tid / w : 0;
+  (void)k;
+  double* tv = lds;         // r: [x^; g]
+  double* part = lds + r;   // P * w <= 1024
+  const double* __restrict__ sp = SPb + T.spb + tid;
+  double pv[SOLVE_PREFETCH];
+#pragma unroll
+  for (int e = 0; e < SOLVE_PREFETCH; ++e) pv[e] = (active && e < E) ? sp[(long long)e * TS] : 0.0;
+  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;
+  // x^ from the forward item of this front (the root turns around here), the ancestors' solution
+  // entries from their backward items: polled one by one, no flag, no fence
+  if (tid < w) {
+    tv[tid] = poll_f64(xhat + T.c0 + tid, info);
+    sent_f64_agent(xhat + T.c0 + tid);  // single consumer: slot ready for the next solve
+  } else if (myrow >= 0) {
+    tv[tid] = poll_f64(ysol + myrow, info);
+  }
+  // the parent's forward item consumed this front's update vector long ago (it precedes the root's turn)
+  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < SOLVE_PREFETCH; ++e)
+    if (e < E) acc = fma(pv[e], tv[min(p + P * e, r - 1)], acc);  // entries beyond row r - 1 are stored as zeros
+  for (int e = SOLVE_PREFETCH; e < E; ++e)
+    if (active) acc = fma(sp[(long long)e * TS], tv[min(p + P * e, r - 1)], acc);
+  if (active) part[tid] = acc;
+  __syncthreads();
+  if (tid < w) {
+    double s2 = 0.0;
+    for (int pp = 0; pp < P; ++pp) s2 += part[pp * w + tid];
+    y[T.c0 + tid] = s2;
+    post_f64(ysol + T.c0 + tid, s2);
+  }
+}
+
+__global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__ items, int nf,
+                                                   const double* __restrict__ SPf, const double* __restrict__ SPb,
+                                                   const long long* __restrict__ xuoff,
+                                                   const int* __restrict__ xinvoff, const int* __restrict__ inv,
+                                                   const int* __restrict__ rows, double* __restrict__ y,
+                                                   double* __restrict__ xhat,
+                                                   double* __restrict__ uvec, double* __restrict__ ysol2, int m,
+                                                   const int* __restrict__ epoch, int* __restrict__ info,
+                                                   const int* __restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * 1024 + 8];
+  if (skip && *skip) return;
+  const int par = *epoch & 1;  // constant during the launch: advanced by the kernel behind it
+  const int b = blockIdx.x;
+  if (b < nf) {
+    const SolveItem& T = items[b];
+    dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info);
+  } else {
+    const SolveItem& T = items[2 * nf - 1 - b];
+    dev_solve_bwd(T, SPb, rows, y, xhat, uvec, ysol2 + (size_t)par * m, lds, info);
+  }
+}
+
+// Solve panels of one front from its factored panel (X = inv(L11) strictly lower + pivots on the
+// diagonal, L21 below): W = L21 X on the matrix cores, then both thread-major copies.  One workgroup
+// (8 waves) per front, X in LDS; a wave owns 16-row strips of L21, requests its whole strip (the A
+// operands of every step) in one batch, and keeps the strip of W (up to 8 tiles of 16 x 16) in its
+// accumulators.  Padding entries of the arenas and the zeros above the diagonal of X are zero from
+// the upload of the plan and never written.
+constexpr int SPB = 512;
+__global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __restrict__ items,
+                                                            const double* __restrict__ L, double* __restrict__ SPf,
+                                                            double* __restrict__ SPb) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const SolveItem& T = items[blockIdx.x];
+  const int w = T.w, r = T.r, u = r - w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nbk = (w + 15) >> 4, wp = nbk << 4;
+  const int ldx = wp + 1;                    // odd leading dimension: column reads of X spread over the banks
+  const double* __restrict__ Pn = L + T.Loff;
+  double* X = lds;                           // wp x wp (ld ldx), unit lower, zero padded
+  double* dinv = X + (size_t)ldx * wp;       // wp
+  double* tile = dinv + wp + (size_t)wave * (16 * 17);  // per wave: one 16 x 16 tile, row stride 17
+  // the first strip of this wave: requested before X is staged, so that both arrive together
+  const int nstrip = (u + 15) >> 4;
+  double av[32];
+  {
+    const int a0 = wave << 4;
+    const bool rowok = wave < nstrip && a0 + li < u;
+    const double* __restrict__ Lr = Pn + w + a0 + li;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const int j = 4 * t + lk;
+      av[t] = (rowok && j < w) ? Lr[(long long)j * r] : 0.0;
+    }
+  }
+  for (int idx = tid; idx < wp * wp; idx += SPB) {
+    const int i = idx % wp, k = idx / wp;
+    double v = (i == k) ? 1.0 : 0.0;
+    if (i < w && k < w && i > k) v = Pn[i + (long long)k * r];
+    X[i + k * ldx] = v;
+  }
+  for (int k = tid; k < wp; k += SPB) dinv[k] = (k < w) ? 1.0 / Pn[k + (long long)k * r] : 1.0;
+  __syncthreads();
+  const int Qf = T.Qf, Pb = T.Pb;
+  const long long TSf = (long long)r * Qf, TSb = (long long)w * Pb;
+  double* __restrict__ sf = SPf + T.spf;
+  double* __restrict__ sb = SPb + T.spb;
+  // update rows: S[w + a, k] = -W[a, k], W = L21 X.  Strip of 16 rows per wave and turn.
+  for (int st = wave; st < nstrip; st += SPB / 64) {
+    const int a0 = st << 4;
+    d4_t acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    // columns j of L21 four at a time (A operand: rows a0 + li, columns j0 + lk); X[j, k] = 0 for j < k:
+    // only the column tiles kt with 16 kt <= j0 + 3 take part
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const int j0 = 4 * t;
+      if (j0 < wp) {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+          if (16 * kt <= j0 + 3 && kt < nbk) acc[kt] = MFMA_F64(av[t], X[(j0 + lk) + (16 * kt + li) * ldx], acc[kt]);
+      }
+    }
+    // the next strip of this wave travels while this one is stored
+    {
+      const int an = (st + SPB / 64) << 4;
+      const bool rowok = st + SPB / 64 < nstrip && an + li < u;
+      const double* __restrict__ Lr = Pn + w + an + li;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const int j = 4 * t + lk;
+        av[t] = (rowok && j < w) ? Lr[(long long)j * r] : 0.0;
+      }
+    }
+    // finished strip: tile by tile through the wave's LDS tile, row-major for the backward copy
+    // (16 consecutive columns per store) and column-major for the forward copy (16 consecutive rows)
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt >= nbk) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = lk + 4 * q, k = 16 * kt + li, i = w + a0 + row;
+        tile[row * 17 + li] = -acc[kt][q];
+        if (a0 + row < u && k < w) sb[(long long)(i / Pb) * TSb + (long long)(i % Pb) * w + k] = -acc[kt][q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = li, col = lk + 4 * q, k = 16 * kt + col, i = w + a0 + row;
+        if (a0 + row < u && k < w) sf[(long long)(k / Qf) * TSf + (long long)(k % Qf) * r + i] = tile[row * 17 + col];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // pivot rows: S[i, k] = X[i, k] (lower triangle); backward copy divided by d_i.  Two passes so that each
+  // copy is written along its contiguous direction (rows i forward, columns k backward).
+  for (int idx = tid; idx < w * w; idx += SPB) {
+    const int i = idx % w, k = idx / w;
+    if (i >= k) sf[(long long)(k / Qf) * TSf + (long long)(k % Qf) * r + i] = X[i + k * ldx];
+  }
+  for (int idx = tid; idx < w * w; idx += SPB) {
+    const int k = idx % w, i = idx / w;
+    if (i >= k) sb[(long long)(i / Pb) * TSb + (long long)(i % Pb) * w + k] = X[i + k * ldx] * dinv[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Saddle-point front / back end: K = [I A^T; A 0].
 //
 // Internally the constraint rows are EQUILIBRATED: A^ = D A with D = diag(2^-e_k), |row k of A^| in
@@ -2674,8 +2933,10 @@ __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __rest
                                                  const double* __restrict__ Ksc, const int* __restrict__ Kc_y,
                                                  const int* __restrict__ perm, SaddleMaps M,
                                                  const double* __restrict__ yp, const double* __restrict__ b,
-                                                 double* __restrict__ z, const int* __restrict__ skip) {
+                                                 double* __restrict__ z, const int* __restrict__ skip,
+                                                 int* __restrict__ epoch) {
   if (skip && *skip) return;
+  if (epoch && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1;  // the fused solve launch before this one is over
   const int sub = threadIdx.x % CL;
   const int cpb = FB / CL;
   for (int j = blockIdx.x * cpb + threadIdx.x / CL; j < n; j += gridDim.x * cpb) {
@@ -3017,7 +3278,9 @@ __global__ __launch_bounds__(FB) void k_axpby(int n, double a, const double* __r
 }
 
 __global__ __launch_bounds__(FB) void k_scatter(long long n, const int* __restrict__ idx,
-                                                const double* __restrict__ in, double* __restrict__ out) {
+                                                const double* __restrict__ in, double* __restrict__ out,
+                                                int* __restrict__ epoch) {
+  if (epoch && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1;
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
     out[idx[i]] = in[i];
 }
@@ -3032,8 +3295,9 @@ __global__ __launch_bounds__(FB) void k_gather_skip(long long n, const int* __re
 }
 __global__ __launch_bounds__(FB) void k_scatter_acc(long long n, const int* __restrict__ idx,
                                                     const double* __restrict__ in, double* __restrict__ out,
-                                                    const int* __restrict__ skip) {
+                                                    const int* __restrict__ skip, int* __restrict__ epoch) {
   if (skip && *skip) return;
+  if (epoch && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1;
   for (long long i = blockIdx.x * (long long)FB + threadIdx.x; i < n; i += (long long)gridDim.x * FB)
     out[idx[i]] += in[i];
 }

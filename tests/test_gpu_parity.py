@@ -561,6 +561,7 @@ def test_wide_fronts_solved_by_several_workgroups(fact):
     K = synth.kkt_full_matrix(N, kc, kr, kd)
     b = np.random.default_rng(4).standard_normal(N)
     fact.set_option("refine_steps", 0)
+    fact.set_option("solve_fused", 0)  # the head / slice workgroups belong to the two-launch kernels
     outs = []
     for wide in (0, 300):
         fact.set_option("wide_min_rows", wide)
@@ -572,6 +573,13 @@ def test_wide_fronts_solved_by_several_workgroups(fact):
         assert fact.info("solve_timeouts") == 0
         assert scaled_residual(K, outs[-1], b) <= 1e-10
     assert rel_err(outs[1], outs[0]) <= 1e-10
+    # fronts of more than 1024 rows do not qualify for the fused launch: the request falls back to these kernels
+    fact.set_option("solve_fused", 1)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("fused_solve") == (1 if fact.info("max_r") <= 1024 else 0)
+    for _ in range(2):
+        fact.solve(b)
+    assert rel_err(fact.solution_raw(0, N), outs[0]) <= 1e-10 and fact.info("solve_timeouts") == 0
 
 
 def test_top_of_tree_solve_variants_agree_bitwise(fact):
@@ -583,6 +591,7 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
     b = np.random.default_rng(2).standard_normal(N)
     fact.set_option("refine_steps", 0)
+    fact.set_option("solve_fused", 0)
     outs = []
     for top_max, prefetch in ((0, 0), (256, 0), (1024, 1)):
         fact.set_option("top_max_fronts", top_max)
@@ -594,6 +603,17 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     K = synth.kkt_full_matrix(N, kc, kr, kd)
     assert scaled_residual(K, outs[0], b) <= 1e-9
+    # the fused forward + backward launch works on another form of the factor ([X; -L21 X] instead of
+    # [X; L21]): same solution to rounding, deterministic from run to run
+    fact.set_option("solve_fused", 1)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("fused_solve") == 1
+    fused = []
+    for _ in range(2):
+        fact.solve(b)
+        fused.append(fact.solution_raw(0, N))
+    assert np.array_equal(fused[0], fused[1])
+    assert rel_err(fused[0], outs[0]) <= 1e-11 and scaled_residual(K, fused[0], b) <= 1e-9
 
 
 def test_solve_sequence_with_changing_right_hand_sides(fact):
@@ -614,6 +634,7 @@ def test_solve_sequence_with_changing_right_hand_sides(fact):
         rhs = [rng.standard_normal(N) * 10.0 ** rng.integers(-3, 4) for _ in range(5)]
         rhs.insert(2, np.zeros(N))
         fact.set_option("refine_steps", 0)
+        fact.set_option("solve_fused", 0)
         outs = {}
         for top_max in (0, opts.get("top_max_fronts", 1024)):
             fact.set_option("top_max_fronts", top_max)
@@ -631,6 +652,17 @@ def test_solve_sequence_with_changing_right_hand_sides(fact):
         a, c = outs.values()
         for x, y in zip(a, c):
             assert np.array_equal(x, y) if "wide_min_rows" not in opts else rel_err(x, y) <= 1e-10
+        # the same sequence through the fused launch (three kinds of sentinel slots: update vectors, x^, ysol)
+        fact.set_option("solve_fused", 1)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("fused_solve") == (1 if fact.info("max_r") <= 1024 else 0)
+        for i, b in enumerate(rhs):
+            if i == 3:
+                fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            fact.solve(b)
+            z = fact.solution_raw(0, N)
+            assert fact.info("solve_timeouts") == 0
+            assert rel_err(z, a[i]) <= 1e-10 and scaled_residual(K, z, b) <= 1e-9
     fact.set_option("top_max_fronts", 1024)
     fact.set_option("wide_min_rows", 1024)
 
