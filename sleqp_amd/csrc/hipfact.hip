@@ -855,7 +855,7 @@ static int upload_plan(hipfact_handle* h) {
       }
       {
         const size_t wp = (size_t)((wmax + 15) & ~15);
-        h->sp_lds = (wp * (wp + 1) + wp + 8 * 16 * 17) * sizeof(double);  // X | 1 / d | one tile per wave
+        h->sp_lds = (wp * (wp + 1) + wp + 8 * 16 * 17 + wp + 1024) * sizeof(double);  // X | 1 / d | tiles | offsets
       }
       if (h->sp_lds <= 160 * 1024) {
         if ((rc = upload(h, h->d_sitems, si))) return rc;

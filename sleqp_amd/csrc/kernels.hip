@@ -2661,6 +2661,10 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
   double* X = lds;                           // wp x wp (ld ldx), unit lower, zero padded
   double* dinv = X + (size_t)ldx * wp;       // wp
   double* tile = dinv + wp + (size_t)wave * (16 * 17);  // per wave: one 16 x 16 tile, row stride 17
+  // where column k of the forward copy and row i of the backward copy start (integer divisions are ~40
+  // instructions each on this hardware: once per column / row instead of once per element)
+  long long* offF = reinterpret_cast<long long*>(dinv + wp + (SPB / 64) * (16 * 17));  // wp
+  long long* offB = offF + wp;                                                          // r
   // the first strip of this wave: requested before X is staged, so that both arrive together
   const int nstrip = (u + 15) >> 4;
   double av[32];
@@ -2674,16 +2678,32 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
       av[t] = (rowok && j < w) ? Lr[(long long)j * r] : 0.0;
     }
   }
-  for (int idx = tid; idx < wp * wp; idx += SPB) {
-    const int i = idx % wp, k = idx / wp;
-    double v = (i == k) ? 1.0 : 0.0;
-    if (i < w && k < w && i > k) v = Pn[i + (long long)k * r];
-    X[i + k * ldx] = v;
+  // X: eight independent loads per thread and batch (a load -> store loop would pay one memory round trip per
+  // element)
+  for (int k0 = wave; k0 < wp; k0 += 8 * (SPB / 64)) {  // eight columns per wave and batch, rows lane, lane + 64
+    double v[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int k = k0 + t * (SPB / 64), i = lane + 64 * h2;
+        v[t][h2] = (i == k) ? 1.0 : 0.0;
+        if (i < w && k < w && i > k) v[t][h2] = Pn[i + (long long)k * r];
+      }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int k = k0 + t * (SPB / 64), i = lane + 64 * h2;
+        if (k < wp && i < wp) X[i + k * ldx] = v[t][h2];
+      }
   }
   for (int k = tid; k < wp; k += SPB) dinv[k] = (k < w) ? 1.0 / Pn[k + (long long)k * r] : 1.0;
-  __syncthreads();
   const int Qf = T.Qf, Pb = T.Pb;
   const long long TSf = (long long)r * Qf, TSb = (long long)w * Pb;
+  for (int k = tid; k < wp; k += SPB) offF[k] = (long long)(k / Qf) * TSf + (long long)(k % Qf) * r;
+  for (int i = tid; i < r; i += SPB) offB[i] = (long long)(i / Pb) * TSb + (long long)(i % Pb) * w;
+  __syncthreads();
   double* __restrict__ sf = SPf + T.spf;
   double* __restrict__ sb = SPb + T.spb;
   // update rows: S[w + a, k] = -W[a, k], W = L21 X.  Strip of 16 rows per wave and turn.
@@ -2723,7 +2743,7 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
       for (int q = 0; q < 4; ++q) {
         const int row = lk + 4 * q, k = 16 * kt + li, i = w + a0 + row;
         tile[row * 17 + li] = -acc[kt][q];
-        if (a0 + row < u && k < w) sb[(long long)(i / Pb) * TSb + (long long)(i % Pb) * w + k] = -acc[kt][q];
+        if (a0 + row < u && k < w) sb[offB[i] + k] = -acc[kt][q];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2731,7 +2751,7 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = li, col = lk + 4 * q, k = 16 * kt + col, i = w + a0 + row;
-        if (a0 + row < u && k < w) sf[(long long)(k / Qf) * TSf + (long long)(k % Qf) * r + i] = tile[row * 17 + col];
+        if (a0 + row < u && k < w) sf[offF[k] + i] = tile[row * 17 + col];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2739,13 +2759,11 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
   }
   // pivot rows: S[i, k] = X[i, k] (lower triangle); backward copy divided by d_i.  Two passes so that each
   // copy is written along its contiguous direction (rows i forward, columns k backward).
-  for (int idx = tid; idx < w * w; idx += SPB) {
-    const int i = idx % w, k = idx / w;
-    if (i >= k) sf[(long long)(k / Qf) * TSf + (long long)(k % Qf) * r + i] = X[i + k * ldx];
-  }
-  for (int idx = tid; idx < w * w; idx += SPB) {
-    const int k = idx % w, i = idx / w;
-    if (i >= k) sb[(long long)(i / Pb) * TSb + (long long)(i % Pb) * w + k] = X[i + k * ldx] * dinv[i];
+  for (int k = wave; k < w; k += SPB / 64)
+    for (int i = k + lane; i < w; i += 64) sf[offF[k] + i] = X[i + k * ldx];
+  for (int i = wave; i < w; i += SPB / 64) {
+    const double di = dinv[i];
+    for (int k = lane; k <= i; k += 64) sb[offB[i] + k] = X[i + k * ldx] * di;
   }
 }
 
