@@ -100,7 +100,7 @@ struct LevelInfo {
   long long itB = 0, itC = 0, itD = 0;  // offsets (in FrontItems) into d_fitems
   int nA = 0, nC = 0, nD = 0;           // number of (front, part) items
   int panel_threads = 512;              // 16 panel rows per wave
-  size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0, lds_asm = 0;
+  size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0, lds_asm = 0, lds_solve_max = 0;
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
@@ -217,10 +217,14 @@ struct hipfact_handle : PlanState {
   std::atomic<int> refcount{1};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;          // solve panels of the finished bottom levels are built beside the top-of-tree launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string error;
   PlanParams prm;
   std::vector<std::unique_ptr<PlanState>> cache;  // inactive plan states, at most plan_cache_max
   int plan_cache_max = 4;
+  bool spanel_side = false;       // solve panels of the bottom levels on a second stream beside k_factor_top (measured: no gain, the
+                                  // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
   bool solve_fused = true;        // one launch for the whole solve tree on the solve panels (when every front qualifies)
   bool assemble_superset = true;  // hipfact_assemble_kkt analyses a superset structure of J instead of K itself
   bool jdev_valid = false;        // pattern of the Jacobian resident in d_jp / d_ji
@@ -508,14 +512,26 @@ static int upload_plan(hipfact_handle* h) {
     li.lds_pivot = (wp + needB) * sizeof(double) + MAXCH * wp * sizeof(int);
     li.lds_panel = (wp + wp * (wp + 1)) * sizeof(double) + MAXCH * wp * sizeof(int);
     li.lds_schur = (wp + needD) * sizeof(double) + 128 * MAXCH * sizeof(int);
-    li.lds_asm = ((size_t)P.max_u + 16) * sizeof(int);
+    {
+      // scatter assembly stages one child's relative indices at a time: the largest child of this level
+      int muc = 0;
+      for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; ++q) {
+        const int s = P.level_sn[q];
+        for (int ci = P.child_ptr[s]; ci < P.child_ptr[s + 1]; ++ci) {
+          const int ch = P.child_idx[ci];
+          muc = std::max(muc, P.sn_r[ch] - (P.sn_c0[ch + 1] - P.sn_c0[ch]));
+        }
+      }
+      li.lds_asm = ((size_t)muc + 16) * sizeof(int);
+    }
     li.lds_fwd = ((size_t)mr + 9 * (size_t)mw + 1024 + 2) * sizeof(double);
     {
       // dev_bwd_front: u + w; dev_bwd_small (u <= 256): 4 ceil(u/4) + (wp + 4) + wp + 256 + ceil(u/2)
       const size_t us = (size_t)std::min(mu, 256);
       li.lds_bwd = std::max((size_t)mu + mw + 2, us + 4 + 2 * wp + 4 + 256 + us / 2 + 2) * sizeof(double);
     }
-    max_lds = std::max({max_lds, li.lds_factor, li.lds_fwd, li.lds_bwd});
+    li.lds_solve_max = std::max(li.lds_fwd, li.lds_bwd);
+    max_lds = std::max({max_lds, li.lds_factor});
     // split when the level cannot fill the chip with one workgroup per front and the fronts are not tiny
     li.split = (li.count <= h->split_max_fronts) && (work >= 2.0e5);
     li.pull = li.split && mch > 0 && h->pull_max_children > 0;  // any number of children (descriptor chains)
@@ -874,11 +890,33 @@ static int upload_plan(hipfact_handle* h) {
       }
     }
   }
-  // the LDS-resident solve vectors of the per-level / two-launch kernels only matter when those run
-  if (!h->fused_solve && max_lds > 160 * 1024) {
-    h->error = "front too large for LDS-resident solve vectors";
-    return HIPFACT_EINTERNAL;
+  // Capacity limits of the LDS-resident working sets (documented in INTEGRATION.md).  Only what can actually
+  // run is checked: the per-level solve kernels below the single-launch top (whose wide fronts are sliced and
+  // need no front-sized buffer), the top kernels' own requirements, and the scatter assembly.
+  {
+    size_t solve_lds = 0, asm_lds = 0;
+    if (!h->fused_solve) {
+      const int ltop = std::min(h->top_level, P.nlevels);
+      for (int l = 0; l < ltop; ++l) solve_lds = std::max(solve_lds, h->levels[l].lds_solve_max);
+      if (ltop < P.nlevels) solve_lds = std::max({solve_lds, h->top_lds_fwd, h->top_lds_bwd});
+    }
+    for (int l = 0; l < P.nlevels; ++l) asm_lds = std::max(asm_lds, h->levels[l].lds_asm);
+    char buf[200];
+    if (solve_lds > 160 * 1024) {
+      snprintf(buf, sizeof buf, "front too large for the LDS-resident solve vectors (%zu KB needed, 160 KB available; "
+               "fronts of up to 1024 rows use the fused solve launch instead)", solve_lds >> 10);
+      h->error = buf;
+      return HIPFACT_EINTERNAL;
+    }
+    if (max_lds > 160 * 1024 || h->ftop_lds > 160 * 1024 || asm_lds > 160 * 1024) {
+      snprintf(buf, sizeof buf, "front too large for the LDS-resident factorisation buffers (%zu KB needed)",
+               std::max({max_lds, h->ftop_lds, asm_lds}) >> 10);
+      h->error = buf;
+      return HIPFACT_EINTERNAL;
+    }
   }
+  HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_assemble),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   for (const void* fn : {reinterpret_cast<const void*>(k_front_pivot<false>), reinterpret_cast<const void*>(k_front_pivot<true>),
                          reinterpret_cast<const void*>(k_front_panel<false>), reinterpret_cast<const void*>(k_front_panel<true>),
                          reinterpret_cast<const void*>(k_front_schur<false>), reinterpret_cast<const void*>(k_front_schur<true>), reinterpret_cast<const void*>(k_factor_top),
@@ -1019,15 +1057,30 @@ static int factor_enqueue(hipfact_handle* h) {
              h->d_child.as<int>(), h->d_info.as<int>(), h->debug_phases);
     }
   }
+  // Solve panels (fused solve): the fronts below the single-launch top of the tree are final here, and that
+  // launch is bound by the tree's critical path with most of the chip idle - their panels (most of the bytes)
+  // are built beside it on a second stream; the fronts of the top levels follow behind it.
+  int sp_done = 0;
+  if (h->fused_solve && h->spanel_side && lsplit < P.nlevels && lsplit > 0 && !h->prof.on && h->side) {
+    sp_done = P.level_ptr[lsplit];
+    HCHECK(h, hipEventRecord(h->ev_fork, st));
+    HCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    hipLaunchKernelGGL(k_build_solve_panels, dim3(sp_done), dim3(SPB), h->sp_lds, h->side, h->d_sitems.as<SolveItem>(),
+                       h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
+    HCHECK(h, hipEventRecord(h->ev_join, h->side));
+  }
   if (lsplit < P.nlevels) {
     int* fl = reinterpret_cast<int*>(h->d_L.as<double>() + P.L_size);  // cleared with the L arena
     LAUNCH(PC_FACTOR_T, k_factor_top, dim3(h->ftop_count), dim3(512), h->ftop_lds, h->d_tfitems.as<TopFItem>(),
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
            fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>());
   }
-  if (h->fused_solve)
-    LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper), dim3(SPB), h->sp_lds, h->d_sitems.as<SolveItem>(),
-           h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
+  if (h->fused_solve) {
+    if (sp_done > 0) HCHECK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    if (P.nsuper > sp_done)
+      LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper - sp_done), dim3(SPB), h->sp_lds,
+             h->d_sitems.as<SolveItem>() + sp_done, h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
+  }
   HCHECK(h, hipGetLastError());
   return HIPFACT_OK;
 }
@@ -1473,7 +1526,10 @@ int hipfact_create(hipfact_handle** out, int device) {
   hipfact_handle* h = new (std::nothrow) hipfact_handle();
   if (!h) return HIPFACT_ENOMEM;
   h->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) {
     g_create_error = std::string("device init: ") + hipGetErrorString(e);
     delete h;
     return HIPFACT_EDEVICE;
@@ -1509,6 +1565,9 @@ int hipfact_free(hipfact_handle** handle) {
     drop_graphs(h);
     h->cache.clear();
     (void)hipStreamDestroy(h->stream);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   }
   delete h;
   return HIPFACT_OK;
@@ -2444,6 +2503,11 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   if (!strcmp(name, "split_max_fronts")) {
     h->split_max_fronts = (int)value;
     invalidate_plans(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "spanel_side")) {
+    h->spanel_side = value != 0.0;
+    drop_graphs(h);
     return HIPFACT_OK;
   }
   if (!strcmp(name, "solve_fused")) {  // 0: the two-launch / per-level solve kernels on the factor panels

@@ -5,6 +5,7 @@ golden vectors."""
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -463,3 +464,38 @@ def test_shim_compiles_against_the_reference_headers(tmp_path):
                "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"), os.path.join(ROOT, "shim", src)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cmake"), reason="reference tree not present")
+def test_overlay_script_registers_the_backend(tmp_path):
+    """scripts/overlay_sleqp.py against (a copy of the three files it edits of) the reference checkout: the backend
+    is registered through add_fact like the others (cmake/SearchFact.cmake:11-83), create_aug_jac is rerouted,
+    running it twice changes nothing more."""
+    import importlib.util
+    import shutil
+
+    spec = importlib.util.spec_from_file_location("overlay_sleqp", os.path.join(ROOT, "scripts", "overlay_sleqp.py"))
+    ov = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ov)
+    text = open("/root/reference/cmake/SearchFact.cmake").read()
+    once = ov.register(text, ["fact/fact_hipfact.c", "aug_jac/aug_jac_hipfact.c"])
+    assert once.count('NAME "HIPFACT"') == 1 and "fact/fact_hipfact.c" in once
+    assert once.index('NAME "HIPFACT"') > once.index('NAME "LAPACK"')            # after the last existing backend
+    assert once.index('NAME "HIPFACT"') < once.index("set(_SLEQP_FACT_VALUES")   # before the list is consumed
+    assert ov.register(once, ["fact/fact_hipfact.c", "aug_jac/aug_jac_hipfact.c"]) == once  # idempotent
+    tp = open("/root/reference/src/main/trial_point.c").read()
+    patched = ov.patch_trial_point(tp)
+    assert patched.count("sleqp_hipfact_aug_jac_create(&solver->aug_jac, problem, settings, NULL") == 2  # AUTO and STANDARD
+    assert "sleqp_standard_aug_jac_create" not in patched and '#include "aug_jac/aug_jac_hipfact.h"' in patched
+    assert "sleqp_reduced_aug_jac_create" in patched  # the PSD route is left alone
+    assert ov.patch_trial_point(patched) == patched
+    # end to end on a scratch tree holding just the touched paths
+    for d in ("cmake", "src/main/fact", "src/main/aug_jac", "src/main/tr"):
+        os.makedirs(tmp_path / d)
+    shutil.copy("/root/reference/cmake/SearchFact.cmake", tmp_path / "cmake")
+    shutil.copy("/root/reference/src/main/trial_point.c", tmp_path / "src/main")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlay_sleqp.py"), str(tmp_path), "--aug-jac", "--tr"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert os.path.isfile(tmp_path / "src/main/fact/fact_hipfact.c") and os.path.isfile(tmp_path / "src/main/tr/tr_hipfact.c")
+    assert 'NAME "HIPFACT"' in open(tmp_path / "cmake/SearchFact.cmake").read()
