@@ -1,0 +1,93 @@
+"""In-kernel timeline of the fused solve launch (k_solve_tree), wall_clock64 stamps per workgroup:
+entry, panel entries requested, dependency wait over, posted.
+
+    python scripts/timeline_tree.py build     # here
+    python scripts/timeline_tree.py run       # on the GPU box (gpurun)
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRATCH = os.path.join(ROOT, "sleqp_amd", "_timeline_build")
+SRC = os.path.join(ROOT, "sleqp_amd", "csrc")
+NB = 4096
+
+
+def build():
+    shutil.rmtree(SCRATCH, ignore_errors=True)
+    shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
+    p = os.path.join(SCRATCH, "kernels.hip")
+    s = open(p).read()
+    s = s.replace("typedef double d4_t __attribute__((ext_vector_type(4)));",
+                  f"__device__ long long g_st[{NB} * 8];\n"
+                  f"#define TRS(slot) if (threadIdx.x == 0) g_st[blockIdx.x * 8 + (slot)] = wall_clock64()\n"
+                  "typedef double d4_t __attribute__((ext_vector_type(4)));", 1)
+    a = s.index("__device__ __forceinline__ void dev_solve_fwd(")
+    b = s.index("// Solve panels of one front from its factored panel")
+    seg = s[a:b]
+    # forward
+    seg = seg.replace("  // front row tid: own right-hand side and, per child, which of its update rows lands here", "  TRS(1);\n  // front row tid: own right-hand side and, per child, which of its update rows lands here", 1)
+    seg = seg.replace("  if (tid < r) f[tid] = f0;\n  __syncthreads();", "  if (tid < r) f[tid] = f0;\n  __syncthreads();\n  TRS(2);", 1)
+    seg = seg.replace("      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);\n  }\n}", "      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);\n  }\n  TRS(3);\n}", 1)
+    # backward
+    seg = seg.replace("  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;", "  TRS(1);\n  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;", 1)
+    seg = seg.replace("  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));\n  __syncthreads();", "  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));\n  __syncthreads();\n  TRS(2);", 1)
+    seg = seg.replace("    post_f64(ysol + T.c0 + tid, s2);\n  }\n}", "    post_f64(ysol + T.c0 + tid, s2);\n  }\n  TRS(3);\n}", 1)
+    seg = seg.replace("  const int par = *epoch & 1;", "  TRS(0);\n  const int par = *epoch & 1;", 1)
+    assert seg.count("TRS(") == 7, seg.count("TRS(")
+    s = s[:a] + seg + s[b:]
+    open(p, "w").write(s)
+    h = os.path.join(SCRATCH, "hipfact.hip")
+    t = open(h).read()
+    t += ('\nextern "C" int hipfact_debug_trace_tree(long long* out) {\n'
+          f"  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_st), sizeof(long long) * {NB} * 8);\n}}\n")
+    open(h, "w").write(t)
+    subprocess.check_call(["make", "-C", SCRATCH])
+    print("built", os.path.join(SCRATCH, "libhipfact.so"))
+
+
+def run():
+    import numpy as np
+
+    os.environ["HIPFACT_LIBRARY"] = os.path.join(SCRATCH, "libhipfact.so")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bench import make_problem
+    from plan_emul import Plan
+    from sleqp_amd import _lib
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    f = HipFact(device=0)
+    f.set_option("use_graph", 0)
+    f.set_option("refine_steps", 0)
+    f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    for _ in range(3):
+        f.solve(b)
+        f.solution_raw(0, 1)
+    lib = _lib.load()
+    out = np.zeros(NB * 8, dtype=np.int64)
+    lib.hipfact_debug_trace_tree.argtypes = [C.c_void_p]
+    assert lib.hipfact_debug_trace_tree(out.ctypes.data_as(C.c_void_p)) == 0
+    nf = int(f.info("nsuper"))
+    t = out.reshape(NB, 8)[: 2 * nf, :4].astype(np.float64)
+    t = (t - t[:, 0].min()) / 100.0  # 100 MHz
+    P = Plan(lib, N, cp, ri, vx)
+    lev = P.sn_level[P.level_sn]  # level of the item at each forward position
+    print("# fused solve launch, us since the first workgroup started.  per level: workgroups, entry (min..max), waited (max), posted (max)")
+    for name, sl, levels in (("forward", slice(0, nf), lev), ("backward", slice(nf, 2 * nf), lev[::-1])):
+        tt = t[sl]
+        print(name)
+        for l in (range(P.nlevels) if name == "forward" else range(P.nlevels - 1, -1, -1)):
+            m = levels == l
+            print(f"  level {l:2d}  fronts {int(m.sum()):4d}  entry {tt[m, 0].min():7.2f} .. {tt[m, 0].max():7.2f}  requested {tt[m, 1].max():7.2f}"
+                  f"  waited {tt[m, 2].max():7.2f}  posted {tt[m, 3].max():7.2f}")
+    print(f"# launch span {t[:, 3].max():.2f} us; forward done {t[:nf, 3].max():.2f}")
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "run"]()

@@ -2547,9 +2547,23 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
   int iv[MAXCH];
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < r) ? inv[T.c_invoff[ch] + tid] : -1;
+  {
+    // all children's entries of this row requested at once (several children usually reach the same
+    // separator rows: one round trip instead of one per child), re-polled only where still pending,
+    // added in child order (deterministic)
+    unsigned long long bits[MAXCH];
 #pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch)
-    if (iv[ch] >= 0) f0 += poll_f64(uvec + T.c_uoff[ch] + iv[ch], info);  // child order: deterministic
+    for (int ch = 0; ch < MAXCH; ++ch)
+      bits[ch] = iv[ch] >= 0 ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(uvec + T.c_uoff[ch] + iv[ch]),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : 0ull;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (iv[ch] >= 0) {
+        if (bits[ch] == SOLVE_SENT) bits[ch] = (unsigned long long)__double_as_longlong(poll_f64(uvec + T.c_uoff[ch] + iv[ch], info));
+        f0 += __longlong_as_double((long long)bits[ch]);
+      }
+  }
   for (int x = T.xbegin; x < T.xend; ++x) {  // fronts with more than MAXCH children (rare)
     const int ia = (tid < r) ? inv[xinvoff[x] + tid] : -1;
     if (ia >= 0) f0 += poll_f64(uvec + xuoff[x] + ia, info);
