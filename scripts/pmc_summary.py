@@ -2,7 +2,7 @@
 
 Units/corrections per MI355X_MICROARCH.md §HBM: the counters are in KiB; on gfx950 FETCH_SIZE reports half
 of the bytes of wide coalesced streaming reads, so the read side is given both raw and x2 (upper bound)."""
-import csv, glob, sys, json
+import csv, glob, hashlib, os, sys, json
 def load(d, name):
     path = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = {}
@@ -18,4 +18,11 @@ for k in sorted(f, key=lambda k: -f[k][1]):
     fc = f[k][1] / f[k][0]; wc = w.get(k, [1, 0.0])[1] / max(w.get(k, [1, 0])[0], 1)
     print("%-26s %7d %14.1f %14.1f %14.1f" % (k[:26], f[k][0], fc, 2 * fc, wc))
     out[k] = {"calls": f[k][0], "fetch_bytes_per_launch_raw": fc * 1024, "fetch_bytes_per_launch_x2": 2 * fc * 1024, "write_bytes_per_launch": wc * 1024}
+# which kernel sources the numbers belong to (bench.py refuses to quote them for other sources)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for name in ("kernels.hip", "hipfact.hip"):
+    h.update(open(os.path.join(root, "sleqp_amd", "csrc", name), "rb").read())
+out["_kernels_sha16"] = h.hexdigest()[:16]
+out["_note"] = "bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); fetch x2 = gfx950 correction for wide coalesced reads (upper bound)"
 json.dump(out, open(sys.argv[3], "w"), indent=1)

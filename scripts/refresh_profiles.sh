@@ -1,15 +1,20 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/ (run on the GPU box through gpurun); the
-# summaries are then copied into profiles/ by hand (see profiles/README.md).
+# summaries are then copied into profiles/ (tracked) by scripts/collect_profiles.py.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r1}
+TAG=${1:-r2}
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ceilings > $REPO/gpurun_out/prof_${TAG}_bench.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/pmc_fetch_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/pmc_write_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings > /dev/null 2>&1
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-ceilings --no-extras"
+# per-kernel time (kernel trace + stats only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $REPO/bench.py $ARGS > $OUT/prof_${TAG}_bench.log 2>&1
+# HBM traffic: counters in passes of their own (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
 cd $REPO
-python scripts/pmc_summary.py gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_summary.txt
-python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-python bench.py --workload uniform_n1e4_m5e3 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3.json 2>> gpurun_out/${TAG}_bench.err
-find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_kernel_stats.csv
+python scripts/pmc_summary.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.txt 2>&1
+find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --workload uniform_n1e4_m5e3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_config3.json 2>> $OUT/${TAG}_bench.err

@@ -264,7 +264,7 @@ struct hipfact_handle : PlanState {
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   Prof prof;
   // shared by all plan states (fixed size, never reallocated: graphs of every state may point at them)
-  DevBuf d_info, d_norms, d_ctl;
+  DevBuf d_info, d_norms, d_ctl, d_tickets;
   PinBuf h_ctl;
   void* h_ctl_dev = nullptr;  // device address of the pinned copy of the control block
   PinBuf h_stage, h_info;
@@ -952,6 +952,8 @@ static int upload_plan(hipfact_handle* h) {
   if (!h->d_ctl.p) {
     HCHECK(h, h->d_ctl.ensure(sizeof(RefineCtl)));
     HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), h->stream));
+    HCHECK(h, h->d_tickets.ensure(64 * 32 * sizeof(int)));  // one cache line per group of 32 residual blocks
+    HCHECK(h, hipMemsetAsync(h->d_tickets.p, 0, 64 * 32 * sizeof(int), h->stream));
   }
   if (!h->h_ctl.p) {
     HCHECK(h, h->h_ctl.ensure(sizeof(RefineCtl)));
@@ -1114,6 +1116,7 @@ static int reset_dataflow_state(hipfact_handle* h) {
   if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
   HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));
+  HCHECK(h, hipMemsetAsync(h->d_tickets.p, 0, 64 * 32 * sizeof(int), st));
   HCHECK(h, hipStreamSynchronize(st));
   memset(h->h_ctl.p, 0, sizeof(RefineCtl));
   h->solve_seq = h->seq_at_factor = 0;
@@ -1249,11 +1252,13 @@ static void residual_async(hipfact_handle* h, const double* b, const double* z, 
     LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
            h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
            h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl,
-           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), first ? 1 : 0, target, minmax_ptr(h));
+           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), h->d_tickets.as<int>(), first ? 1 : 0, target,
+           minmax_ptr(h));
   } else {
     LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(), h->d_Ki.as<int>(),
            h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(), h->d_Tsrc.as<int>(), b, z, res, ctl,
-           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), first ? 1 : 0, target, minmax_ptr(h));
+           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), h->d_tickets.as<int>(), first ? 1 : 0, target,
+           minmax_ptr(h));
   }
 }
 

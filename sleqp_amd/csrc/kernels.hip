@@ -3017,7 +3017,8 @@ __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __rest
 __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 
 __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, RefineCtl* __restrict__ hctl,
-                                              double* __restrict__ partials, int first, double target,
+                                              double* __restrict__ partials, int* __restrict__ tickets, int first,
+                                              double target,
                                               const unsigned long long* __restrict__ minmax, double mr, double mb,
                                               double mz) {
   __shared__ double sh[3][FB / 64];
@@ -3048,8 +3049,17 @@ __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, Refin
     __hip_atomic_store(&partials[3 * blockIdx.x + 1], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&partials[3 * blockIdx.x + 2], mz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (ticket == (int)gridDim.x - 1);
+    // two-level election (2048 increments of ONE word serialise for tens of microseconds): groups of 32
+    // blocks take a ticket on their own word (one cache line each), the last of a group on the global one
+    const int grp = blockIdx.x >> 5, ngrp = ((int)gridDim.x + 31) >> 5;
+    const int gsize = min(32, (int)gridDim.x - (grp << 5));
+    int* gticket = tickets + 32 * grp;
+    is_last = 0;
+    if (__hip_atomic_fetch_add(gticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(gticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int ticket = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = (ticket == ngrp - 1);
+    }
   }
   __syncthreads();
   if (!is_last) return;
@@ -3144,7 +3154,7 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
                                                         const double* __restrict__ b, const double* __restrict__ z,
                                                         double* __restrict__ res, RefineCtl* __restrict__ ctl,
                                                         RefineCtl* __restrict__ hctl, double* __restrict__ partials,
-                                                        int first, double target,
+                                                        int* __restrict__ tickets, int first, double target,
                                                         const unsigned long long* __restrict__ minmax) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
@@ -3212,7 +3222,7 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
       }
     }
   }
-  if (ctl) refine_decide(ctl, hctl, partials, first, target, minmax, mr, mb, mz);
+  if (ctl) refine_decide(ctl, hctl, partials, tickets, first, target, minmax, mr, mb, mz);
 }
 
 // Generic mode residual: res = b - (L + L^T - diag) z with L lower CSC and its
@@ -3223,7 +3233,7 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
                                                      const double* __restrict__ b, const double* __restrict__ z,
                                                      double* __restrict__ res, RefineCtl* __restrict__ ctl,
                                                      RefineCtl* __restrict__ hctl, double* __restrict__ partials,
-                                                     int first, double target,
+                                                     int* __restrict__ tickets, int first, double target,
                                                      const unsigned long long* __restrict__ minmax) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
@@ -3242,7 +3252,7 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
       mz = fmax(mz, fabs(z[j]));
     }
   }
-  if (ctl) refine_decide(ctl, hctl, partials, first, target, minmax, mr, mb, mz);
+  if (ctl) refine_decide(ctl, hctl, partials, tickets, first, target, minmax, mr, mb, mz);
 }
 
 // y += a x, or nothing when *skip is set
