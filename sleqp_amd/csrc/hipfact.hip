@@ -264,7 +264,7 @@ struct hipfact_handle : PlanState {
   int info_host[INFO_WORDS] = {0, 0, 0, 0};
   Prof prof;
   // shared by all plan states (fixed size, never reallocated: graphs of every state may point at them)
-  DevBuf d_info, d_norms, d_ctl, d_tickets;
+  DevBuf d_info, d_norms, d_ctl;
   PinBuf h_ctl;
   void* h_ctl_dev = nullptr;  // device address of the pinned copy of the control block
   PinBuf h_stage, h_info;
@@ -952,8 +952,6 @@ static int upload_plan(hipfact_handle* h) {
   if (!h->d_ctl.p) {
     HCHECK(h, h->d_ctl.ensure(sizeof(RefineCtl)));
     HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), h->stream));
-    HCHECK(h, h->d_tickets.ensure(64 * 32 * sizeof(int)));  // one cache line per group of 32 residual blocks
-    HCHECK(h, hipMemsetAsync(h->d_tickets.p, 0, 64 * 32 * sizeof(int), h->stream));
   }
   if (!h->h_ctl.p) {
     HCHECK(h, h->h_ctl.ensure(sizeof(RefineCtl)));
@@ -1116,7 +1114,6 @@ static int reset_dataflow_state(hipfact_handle* h) {
   if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
   HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));
-  HCHECK(h, hipMemsetAsync(h->d_tickets.p, 0, 64 * 32 * sizeof(int), st));
   HCHECK(h, hipStreamSynchronize(st));
   memset(h->h_ctl.p, 0, sizeof(RefineCtl));
   h->solve_seq = h->seq_at_factor = 0;
@@ -1240,7 +1237,9 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
 }
 
 // grid of the residual kernels (= number of partial maxima they leave)
-static inline int resid_blocks(const Plan& P) { return P.saddle ? nblocks((long long)P.N * 8, 2048) : nblocks(P.N, 2048); }
+static inline int resid_blocks(const Plan& P) {  // saddle: an even number >= 2 (columns of K | rows of A)
+  return P.saddle ? std::max(2, nblocks((long long)P.N * 8, 2048) & ~1) : nblocks(P.N, 2048);
+}
 
 // res = b - K z; updates the refinement control block (first: the residual of the first pass)
 static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool first) {
@@ -1251,15 +1250,15 @@ static void residual_async(hipfact_handle* h, const double* b, const double* z, 
   if (P.saddle) {
     LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
            h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
-           h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl,
-           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), h->d_tickets.as<int>(), first ? 1 : 0, target,
-           minmax_ptr(h));
+           h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl, h->d_norms.as<double>(),
+           first ? 1 : 0);
   } else {
     LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(), h->d_Ki.as<int>(),
            h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(), h->d_Tsrc.as<int>(), b, z, res, ctl,
-           static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(), h->d_tickets.as<int>(), first ? 1 : 0, target,
-           minmax_ptr(h));
+           h->d_norms.as<double>(), first ? 1 : 0);
   }
+  LAUNCH(PC_RESID, k_refine_decide, dim3(1), dim3(FB), 0, ctl, static_cast<RefineCtl*>(h->h_ctl_dev),
+         h->d_norms.as<double>(), resid_blocks(P), first ? 1 : 0, target, minmax_ptr(h));
 }
 
 static void drop_graphs(hipfact_handle* h) { h->graphs.clear(); }

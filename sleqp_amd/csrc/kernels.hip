@@ -3016,13 +3016,9 @@ __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __rest
 //   systems are accepted after the first pass and ill conditioned ones are refined to the limit.
 __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 
-__device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, RefineCtl* __restrict__ hctl,
-                                              double* __restrict__ partials, int* __restrict__ tickets, int first,
-                                              double target,
-                                              const unsigned long long* __restrict__ minmax, double mr, double mb,
-                                              double mz) {
+// block partials of a residual kernel: plain stores, the decision is taken by the kernel behind it
+__device__ __forceinline__ void refine_partials(double* __restrict__ partials, double mr, double mb, double mz) {
   __shared__ double sh[3][FB / 64];
-  __shared__ int is_last;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -3036,51 +3032,32 @@ __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, Refin
     sh[2][tid >> 6] = mz;
   }
   __syncthreads();
-  // No fences (an agent-scope release writes back the dirty lines of L2, an acquire invalidates
-  // them): the partials travel as agent-scope atomic stores / loads, which operate on L2 itself, and
-  // the ticket is taken after the stores have been acknowledged.
   if (tid == 0) {
     for (int q = 1; q < FB / 64; ++q) {
       mr = nanmax(mr, sh[0][q]);
       mb = nanmax(mb, sh[1][q]);
       mz = nanmax(mz, sh[2][q]);
     }
-    __hip_atomic_store(&partials[3 * blockIdx.x], mr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&partials[3 * blockIdx.x + 1], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&partials[3 * blockIdx.x + 2], mz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // two-level election (2048 increments of ONE word serialise for tens of microseconds): groups of 32
-    // blocks take a ticket on their own word (one cache line each), the last of a group on the global one
-    const int grp = blockIdx.x >> 5, ngrp = ((int)gridDim.x + 31) >> 5;
-    const int gsize = min(32, (int)gridDim.x - (grp << 5));
-    int* gticket = tickets + 32 * grp;
-    is_last = 0;
-    if (__hip_atomic_fetch_add(gticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
-      __hip_atomic_store(gticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int ticket = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = (ticket == ngrp - 1);
-    }
+    partials[3 * blockIdx.x] = mr;
+    partials[3 * blockIdx.x + 1] = mb;
+    partials[3 * blockIdx.x + 2] = mz;
   }
-  __syncthreads();
-  if (!is_last) return;
+}
+
+// One block: reduces the partial maxima of the residual kernel in front of it and updates the control block.
+// (An election of the last block inside the residual kernel costs more: thousands of blocks each end with a
+// dependent store -> ticket round trip, and increments of one word serialise.)
+__global__ __launch_bounds__(FB) void k_refine_decide(RefineCtl* __restrict__ ctl, RefineCtl* __restrict__ hctl,
+                                                      const double* __restrict__ partials, int nblk, int first,
+                                                      double target, const unsigned long long* __restrict__ minmax) {
+  if (!first && ctl->done) return;
+  __shared__ double sh[3][FB / 64];
+  const int tid = threadIdx.x;
   double r = 0.0, bb = 0.0, zz = 0.0;
-  {
-    constexpr int PU = 8;  // resid grids hold at most 2048 blocks
-    double pr[PU], pb[PU], pz[PU];
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-      const int q = tid + u * FB;
-      const bool in = q < (int)gridDim.x;
-      pr[u] = in ? __hip_atomic_load(&partials[3 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      pb[u] = in ? __hip_atomic_load(&partials[3 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      pz[u] = in ? __hip_atomic_load(&partials[3 * q + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-      r = nanmax(r, pr[u]);
-      bb = nanmax(bb, pb[u]);
-      zz = nanmax(zz, pz[u]);
-    }
+  for (int q = tid; q < nblk; q += FB) {
+    r = nanmax(r, partials[3 * q]);
+    bb = nanmax(bb, partials[3 * q + 1]);
+    zz = nanmax(zz, partials[3 * q + 2]);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -3088,7 +3065,6 @@ __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, Refin
     bb = nanmax(bb, __shfl_down(bb, o, 64));
     zz = nanmax(zz, __shfl_down(zz, o, 64));
   }
-  __syncthreads();
   if ((tid & 63) == 0) {
     sh[0][tid >> 6] = r;
     sh[1][tid >> 6] = bb;
@@ -3129,7 +3105,6 @@ __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, Refin
     ctl->kappa = kappa;
     ctl->status = status;
     ctl->seq = seq;
-    __hip_atomic_store(&ctl->counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ctl->done = done;  // read by the kernels of the next pass: a kernel boundary away
     // copy for the host in pinned memory (visible after the stream has been synchronised): no copy node
     hctl->iters = iters;
@@ -3139,7 +3114,8 @@ __device__ __forceinline__ void refine_decide(RefineCtl* __restrict__ ctl, Refin
     hctl->kappa = kappa;
     hctl->status = status;
     hctl->done = done;
-    __hip_atomic_store(&hctl->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // last: the host may peek without a sync
+    // last, relaxed: the stores of one thread to host memory arrive in order (the host may peek without a sync)
+    __hip_atomic_store(&hctl->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -3152,18 +3128,19 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
                                                         const double* __restrict__ Ar_val,
                                                         const int* __restrict__ perm, SaddleMaps M,
                                                         const double* __restrict__ b, const double* __restrict__ z,
-                                                        double* __restrict__ res, RefineCtl* __restrict__ ctl,
-                                                        RefineCtl* __restrict__ hctl, double* __restrict__ partials,
-                                                        int* __restrict__ tickets, int first, double target,
-                                                        const unsigned long long* __restrict__ minmax) {
+                                                        double* __restrict__ res, const RefineCtl* __restrict__ ctl,
+                                                        double* __restrict__ partials, int first) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
-  {
+  // The two sweeps are chains of three dependent gathers each (pointer -> index / value -> vector entry);
+  // the first half of the grid takes the columns of K, the second half the rows of A, side by side.
+  const int nbx = (int)gridDim.x >> 1;
+  if ((int)blockIdx.x < nbx) {
     const int sub = threadIdx.x % CL;
     const int cpb = FB / CL;
-    const int iters = (n + gridDim.x * cpb - 1) / (gridDim.x * cpb);
+    const int iters = (n + nbx * cpb - 1) / (nbx * cpb);
     for (int it = 0; it < iters; ++it) {  // uniform trip count (the shuffles need whole groups)
-      const int j = (it * gridDim.x + blockIdx.x) * cpb + threadIdx.x / CL;
+      const int j = (it * nbx + blockIdx.x) * cpb + threadIdx.x / CL;
       double s = 0.0;
       if (j < n) {
         const int e1 = Kp[j + 1];
@@ -3194,13 +3171,13 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
         mz = fmax(mz, fabs(zj));
       }
     }
-  }
-  {
+  } else {
+    const int nby = (int)gridDim.x - nbx, by = (int)blockIdx.x - nbx;
     const int sub = threadIdx.x % RL;
     const int rpb = FB / RL;
-    const int iters = (m + gridDim.x * rpb - 1) / (gridDim.x * rpb);
+    const int iters = (m + nby * rpb - 1) / (nby * rpb);
     for (int it = 0; it < iters; ++it) {
-      const int k = (it * gridDim.x + blockIdx.x) * rpb + threadIdx.x / RL;
+      const int k = (it * nby + by) * rpb + threadIdx.x / RL;
       double s = 0.0;
       if (k < m) {
         const int p1 = Ar_ptr[k + 1];
@@ -3222,7 +3199,7 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
       }
     }
   }
-  if (ctl) refine_decide(ctl, hctl, partials, tickets, first, target, minmax, mr, mb, mz);
+  if (ctl) refine_partials(partials, mr, mb, mz);
 }
 
 // Generic mode residual: res = b - (L + L^T - diag) z with L lower CSC and its
@@ -3231,10 +3208,8 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
                                                      const double* __restrict__ Kval, const int* __restrict__ Tp,
                                                      const int* __restrict__ Ti, const int* __restrict__ Tsrc,
                                                      const double* __restrict__ b, const double* __restrict__ z,
-                                                     double* __restrict__ res, RefineCtl* __restrict__ ctl,
-                                                     RefineCtl* __restrict__ hctl, double* __restrict__ partials,
-                                                     int* __restrict__ tickets, int first, double target,
-                                                     const unsigned long long* __restrict__ minmax) {
+                                                     double* __restrict__ res, const RefineCtl* __restrict__ ctl,
+                                                     double* __restrict__ partials, int first) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
   const int iters = (N + gridDim.x * FB - 1) / (gridDim.x * FB);
@@ -3252,7 +3227,7 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
       mz = fmax(mz, fabs(z[j]));
     }
   }
-  if (ctl) refine_decide(ctl, hctl, partials, tickets, first, target, minmax, mr, mb, mz);
+  if (ctl) refine_partials(partials, mr, mb, mz);
 }
 
 // y += a x, or nothing when *skip is set
