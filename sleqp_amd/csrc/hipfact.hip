@@ -251,6 +251,12 @@ struct hipfact_handle : PlanState {
   RefineCtl last_ctl = {1, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
   int solve_seq = 0;             // solves with a residual queued since the control block was last cleared
   bool use_graph = true;         // replay captured hipGraphs instead of re-enqueueing ~100 launches
+  // The single-launch dataflow kernels rely on workgroups being dispatched in index order (observed on every
+  // gfx9 part, documented nowhere).  Their spins are bounded; should one ever time out, the handle falls back for
+  // good to the per-level launches (same arithmetic, no cross-workgroup waits) and repeats the work at once.
+  bool no_dataflow = false;
+  int fake_timeouts = 0;         // test hook: the next reads of the info words report a timeout
+  long dataflow_fallbacks = 0;
   int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
@@ -1024,7 +1030,7 @@ static int factor_enqueue(hipfact_handle* h) {
   if (P.saddle && h->maps_on && P.m > 0)
     LAUNCH(PC_GATHER, k_diag_inactive, dim3(nblocks(P.m)), dim3(FB), 0, P.m, h->d_perm.as<int>(), h->d_cmap.as<int>(),
            h->d_diag_target.as<long long>(), h->d_L.as<double>());
-  const int lsplit = h->debug_phases == 15 ? std::min(h->ftop_level, P.nlevels) : P.nlevels;
+  const int lsplit = (h->debug_phases == 15 && !h->no_dataflow) ? std::min(h->ftop_level, P.nlevels) : P.nlevels;
   for (int l = 0; l < lsplit; ++l) {
     const LevelInfo& li = h->levels[l];
     const int* it = h->d_items.as<int>();
@@ -1061,7 +1067,7 @@ static int factor_enqueue(hipfact_handle* h) {
   // launch is bound by the tree's critical path with most of the chip idle - their panels (most of the bytes)
   // are built beside it on a second stream; the fronts of the top levels follow behind it.
   int sp_done = 0;
-  if (h->fused_solve && h->spanel_side && lsplit < P.nlevels && lsplit > 0 && !h->prof.on && h->side) {
+  if (h->fused_solve && !h->no_dataflow && h->spanel_side && lsplit < P.nlevels && lsplit > 0 && !h->prof.on && h->side) {
     sp_done = P.level_ptr[lsplit];
     HCHECK(h, hipEventRecord(h->ev_fork, st));
     HCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -1075,7 +1081,7 @@ static int factor_enqueue(hipfact_handle* h) {
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
            fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>());
   }
-  if (h->fused_solve) {
+  if (h->fused_solve && !h->no_dataflow) {
     if (sp_done > 0) HCHECK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     if (P.nsuper > sp_done)
       LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper - sp_done), dim3(SPB), h->sp_lds,
@@ -1129,14 +1135,26 @@ static int check_info(hipfact_handle* h, const char* phase = "factorisation") {
   HCHECK(h, hipStreamSynchronize(h->stream));
   memcpy(h->info_host, h->h_info.p, INFO_WORDS * sizeof(int));
   h->factor_checked = true;
+  if (h->fake_timeouts > 0) {
+    --h->fake_timeouts;
+    h->info_host[INFO_TIMEOUT] += 1;
+  }
   char buf[200];
   if (h->info_host[INFO_TIMEOUT] != 0) {
     snprintf(buf, sizeof buf, "dependency wait timed out inside the single-launch %s kernels (%d waits)", phase,
              h->info_host[INFO_TIMEOUT]);
-    h->factored = false;
+    const bool in_solve = !strcmp(phase, "solve");
+    if (!in_solve) h->factored = false;  // a solve does not touch the factor
     h->solved = false;
     const int rc = reset_dataflow_state(h);
     h->error = buf;
+    if (!h->no_dataflow) {
+      // from now on: per-level launches only (captured graphs hold the dataflow launches: drop them all)
+      h->no_dataflow = true;
+      h->dataflow_fallbacks++;
+      h->graphs.clear();
+      for (auto& st2 : h->cache) st2->graphs.clear();
+    }
     return rc ? rc : HIPFACT_EINTERNAL;
   }
   if (h->info_host[INFO_ZERO_PIVOT] > 0) {
@@ -1168,7 +1186,7 @@ static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
 // every launch into a no-op (correction passes of a solve that has already converged)
 static void solve_m_async(hipfact_handle* h, const int* skip) {
   const Plan& P = h->plan;
-  if (h->fused_solve) {
+  if (h->fused_solve && !h->no_dataflow) {
     LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
            h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
            h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
@@ -1176,7 +1194,7 @@ static void solve_m_async(hipfact_handle* h, const int* skip) {
            h->d_info.as<int>(), skip);
     return;
   }
-  const int ltop = std::min(h->top_level, P.nlevels);
+  const int ltop = h->no_dataflow ? P.nlevels : std::min(h->top_level, P.nlevels);
   for (int l = 0; l < ltop; ++l) {
     const LevelInfo& li = h->levels[l];
     LAUNCH(PC_FWD, k_fwd_level, dim3(li.count), dim3(SB), li.lds_fwd, h->d_sn.as<SnDesc>(),
@@ -1209,7 +1227,7 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
   const Plan& P = h->plan;
   if (h->N_ext == 0) return;
   // fused solve launch: the kernel behind it advances the epoch of its double-buffered exchange slots
-  int* epoch = (h->fused_solve && P.m > 0) ? h->d_epoch.as<int>() : nullptr;
+  int* epoch = (h->fused_solve && !h->no_dataflow && P.m > 0) ? h->d_epoch.as<int>() : nullptr;
   if (P.saddle) {
     const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
@@ -1484,6 +1502,20 @@ static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* r
   return HIPFACT_OK;
 }
 
+// factorisation + verdict; a timed-out dataflow launch is repeated once on the per-level path (fresh launches,
+// same process)
+static int factor_and_check(hipfact_handle* h) {
+  int rc = factor_async(h);
+  if (rc) return rc;
+  const bool could_fall_back = !h->no_dataflow;
+  rc = check_info(h);
+  if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->info_host[INFO_TIMEOUT] != 0) {
+    if ((rc = factor_async(h))) return rc;
+    rc = check_info(h);
+  }
+  return rc;
+}
+
 static int enter(hipfact_handle* h) {
   if (!h) return HIPFACT_EINVAL;
   hipError_t e = hipSetDevice(h->device);
@@ -1594,8 +1626,7 @@ int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* r
     memcpy(h->h_stage.p, vals, nnz * sizeof(double));
     HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->h_stage.p, nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
-  if ((rc = factor_async(h))) return rc;
-  return check_info(h);
+  return factor_and_check(h);
 }
 
 int hipfact_refactor_device(hipfact_handle* h, const double* d_vals) {
@@ -1694,7 +1725,17 @@ int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
   HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
   HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
-  if ((rc = check_info(h, "solve"))) return rc;  // synchronises
+  const bool could_fall_back = !h->no_dataflow;
+  rc = check_info(h, "solve");  // synchronises
+  if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->factored && h->last_b && h->last_z) {
+    // the sweep timed out: the same solve once more through the per-level kernels
+    if ((rc = solve_async(h, h->last_b, h->last_z))) return rc;
+    if ((rc = finish_solve(h))) return rc;
+    HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
+                             h->stream));
+    rc = check_info(h, "solve");
+  }
+  if (rc) return rc;
   memcpy(out, h->h_stage.p, cnt * sizeof(double));
   return HIPFACT_OK;
 }
@@ -1894,8 +1935,7 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
     h->N_ext = N;
     if (nnz > 0)
       HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = factor_async(h))) return rc;
-    return check_info(h);
+    return factor_and_check(h);
   }
   // ---- superset path: find a plan whose structure covers the working set's constraint rows
   auto covers = [&](const PlanState& s) {
@@ -1959,8 +1999,7 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
                      h->d_vmap.as<int>(), h->d_cmap.as<int>());
   HCHECK(h, hipGetLastError());
   (void)P;
-  if ((rc = factor_async(h))) return rc;
-  return check_info(h);
+  return factor_and_check(h);
 }
 
 // ---------------------------------------------------------------------------
@@ -2509,6 +2548,10 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     invalidate_plans(h);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "debug_fake_timeout")) {  // test hook for the fallback to the per-level launches
+    h->fake_timeouts = (int)value;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "spanel_side")) {
     h->spanel_side = value != 0.0;
     drop_graphs(h);
@@ -2616,7 +2659,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("fused_solve", h->fused_solve) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)
