@@ -144,6 +144,19 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
                          const double* j_vals, const int* var_index, const int* cons_index, int working_set_size,
                          int* k_nnz, int* k_colptr, int* k_rowidx, double* k_vals);
 
+/* ---- the sparse reduced matrix (PSD route) -------------------------------- */
+
+/* Replaces the assembler of the reduced augmented Jacobian (compute_reduced_matrix,
+ * aug_jac/reduced_aug_jac.c:323-377: O(|W|^2) merge-joins that push EVERY (row, col) pair, i.e. a dense
+ * lower triangle, with an int overflow at |W| >= 46341, :271): S = A_W A_W^T as a SPARSE lower-triangular
+ * CSC matrix in working-set row order, computed on the device from the product lists of the symbolic plan
+ * (one fixed-order sum per structural entry of S).  This is the matrix the saddle mode factorises (after
+ * equilibration): the device AugJac of shim/aug_jac_hipfact.c is at the same time the sparse, correct
+ * reduced path - min-norm / LSQ / projection are solved through the Cholesky factor of S.
+ * Valid after hipfact_set_matrix of a saddle matrix.  Two calls: with colptr == NULL only *nnz is
+ * returned; then colptr (|W| + 1), rowidx and vals (*nnz) are filled. */
+int hipfact_reduced_matrix(hipfact_handle* h, int* nnz, int* colptr, int* rowidx, double* vals);
+
 /* ---- sparse matrix-vector products ------------------------------------- */
 
 typedef struct hipfact_spmat hipfact_spmat;

@@ -10,6 +10,7 @@ What it does (INTEGRATION.md sections 1, 2 and 6):
   * --aug-jac: copies shim/aug_jac_hipfact.{c,h} to src/main/aug_jac/, adds the source to the HIPFACT backend
     and patches create_aug_jac (trial_point.c:105-108) to create the device-assembly AugJac
   * --tr: copies shim/tr_hipfact.{c,h} to src/main/tr/ and adds the source to the backend
+  * --mat: copies shim/mat_hipfact.{c,h} to src/main/sparse/ and adds the source to the backend
 Then configure with  cmake -DSLEQP_FACT=HIPFACT -DHIPFACT_ROOT=<this repository> ...
 The script is idempotent; --dry-run prints what would change and touches nothing.
 """
@@ -27,7 +28,7 @@ TRIAL_POINT_NEW = ("sleqp_hipfact_aug_jac_create(&solver->aug_jac, problem, sett
                    "factorised on the device instead of the standard AugJac over solver->fact */)")
 
 
-def plan(sleqp, aug_jac, tr):
+def plan(sleqp, aug_jac, tr, mat=False):
     copies = [("shim/fact_hipfact.c", "src/main/fact/fact_hipfact.c"),
               ("shim/fact_hipfact.h", "src/main/fact/fact_hipfact.h"),
               ("shim/SearchFactHIPFACT.cmake", "cmake/SearchFactHIPFACT.cmake")]
@@ -39,6 +40,9 @@ def plan(sleqp, aug_jac, tr):
     if tr:
         copies += [("shim/tr_hipfact.c", "src/main/tr/tr_hipfact.c"), ("shim/tr_hipfact.h", "src/main/tr/tr_hipfact.h")]
         sources.append("tr/tr_hipfact.c")
+    if mat:
+        copies += [("shim/mat_hipfact.c", "src/main/sparse/mat_hipfact.c"), ("shim/mat_hipfact.h", "src/main/sparse/mat_hipfact.h")]
+        sources.append("sparse/mat_hipfact.c")
     return copies, sources
 
 
@@ -73,13 +77,14 @@ def main():
     ap.add_argument("sleqp")
     ap.add_argument("--aug-jac", action="store_true")
     ap.add_argument("--tr", action="store_true")
+    ap.add_argument("--mat", action="store_true", help="also copy shim/mat_hipfact.{c,h} (device products of SleqpMat)")
     ap.add_argument("--dry-run", action="store_true")
     args = ap.parse_args()
     sleqp = os.path.abspath(args.sleqp)
     search = os.path.join(sleqp, "cmake", "SearchFact.cmake")
     if not os.path.isfile(search):
         raise SystemExit(f"{search} not found")
-    copies, sources = plan(sleqp, args.aug_jac, args.tr)
+    copies, sources = plan(sleqp, args.aug_jac, args.tr, args.mat)
     for src, dst in copies:
         print(("would copy " if args.dry_run else "copy ") + f"{src} -> {dst}")
         if not args.dry_run:

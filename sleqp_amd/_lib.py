@@ -28,7 +28,7 @@ SYMBOLS = [
     "hipfact_create", "hipfact_free", "hipfact_retain", "hipfact_last_error", "hipfact_set_matrix", "hipfact_solve_sparse",
     "hipfact_solve_dense", "hipfact_solution", "hipfact_condition", "hipfact_refactor_device",
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_check", "hipfact_stream",
-    "hipfact_assemble_kkt", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
+    "hipfact_assemble_kkt", "hipfact_reduced_matrix", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
     "hipfact_spmat_mult_vec", "hipfact_spmat_mult_vec_trans", "hipfact_spmat_mult_vec_sym",
     "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_tr_solve", "hipfact_tridiag_tr", "hipfact_set_option", "hipfact_get_info", "hipfact_debug_copy", "hipfact_plan_create",
     "hipfact_plan_free", "hipfact_plan_error", "hipfact_plan_array", "hipfact_plan_scalar",
@@ -71,6 +71,7 @@ def load() -> C.CDLL:
     lib.hipfact_check.argtypes = [vp]
     lib.hipfact_stream.argtypes = [vp, C.POINTER(vp)]
     lib.hipfact_assemble_kkt.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, C.POINTER(ci), vp, vp, vp]
+    lib.hipfact_reduced_matrix.argtypes = [vp, C.POINTER(ci), vp, vp, vp]
     lib.hipfact_spmat_create.argtypes = [vp, ci, ci, vp, vp, vp, C.POINTER(vp)]
     lib.hipfact_spmat_update_values.argtypes = [vp, vp]
     lib.hipfact_spmat_free.argtypes = [C.POINTER(vp)]

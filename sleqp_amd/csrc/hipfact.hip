@@ -2003,6 +2003,82 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
 }
 
 // ---------------------------------------------------------------------------
+int hipfact_reduced_matrix(hipfact_handle* h, int* nnz_out, int* colptr, int* rowidx, double* vals) {
+  int rc = enter(h);
+  if (rc) return rc;
+  const Plan& P = h->plan;
+  if (!h->have_plan || !P.saddle || h->maps_on || !nnz_out) {
+    h->error = "hipfact_reduced_matrix: needs a saddle matrix set with hipfact_set_matrix";
+    return HIPFACT_ESTATE;
+  }
+  const int m = P.m;
+  const long long nM = (long long)P.Mi.size();
+  if (nM >= (1LL << 31)) {
+    h->error = "hipfact_reduced_matrix: more than 2^31 entries";
+    return HIPFACT_EINVAL;
+  }
+  *nnz_out = (int)nM;
+  if (!colptr) return HIPFACT_OK;
+  if (!rowidx || !vals) return HIPFACT_EINVAL;
+  // values: the product lists once more, on the caller's (unscaled) values, into a plain array in M's order
+  DevBuf d_val, d_iota;
+  std::vector<double> sval((size_t)nM);
+  if (nM > 0) {
+    HCHECK(h, d_val.ensure((size_t)nM * sizeof(double)));
+    const int nb = nblocks(nM, 1 << 16);
+#define RM_LAUNCH(IDX, PK)                                                                                            \
+  {                                                                                                                   \
+    std::vector<IDX> iota((size_t)nM);                                                                                \
+    for (long long e = 0; e < nM; ++e) iota[(size_t)e] = (IDX)e;                                                       \
+    HCHECK(h, d_iota.ensure((size_t)nM * sizeof(IDX)));                                                               \
+    HCHECK(h, hipMemcpyAsync(d_iota.p, iota.data(), (size_t)nM * sizeof(IDX), hipMemcpyHostToDevice, h->stream));     \
+    hipLaunchKernelGGL((k_mvals_prod<IDX, PK>), dim3(nb), dim3(FB), 0, h->stream, nM, h->d_prod_ptr.as<IDX>(),        \
+                       h->d_prod_a.as<int>(), h->d_prod_b.as<int>(), d_iota.as<IDX>(), h->d_Kval.as<double>(),         \
+                       d_val.as<double>(), 0LL, 0, h->d_Ar_src.as<int>(), h->d_Ar_val.as<double>());                   \
+    HCHECK(h, hipStreamSynchronize(h->stream));                                                                       \
+  }
+    if (h->idx32 && h->prod_packed)
+      RM_LAUNCH(unsigned int, true)
+    else if (h->idx32)
+      RM_LAUNCH(unsigned int, false)
+    else if (h->prod_packed)
+      RM_LAUNCH(long long, true)
+    else
+      RM_LAUNCH(long long, false)
+#undef RM_LAUNCH
+    HCHECK(h, hipMemcpy(sval.data(), d_val.p, (size_t)nM * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  // pivot order -> working-set order, lower triangle, rows ascending per column
+  std::vector<int> cnt((size_t)m + 1, 0);
+  for (int k = 0; k < m; ++k)
+    for (long long e = P.Mp[k]; e < P.Mp[k + 1]; ++e) {
+      const int r1 = P.perm[P.Mi[e]], r2 = P.perm[k];
+      ++cnt[(size_t)std::min(r1, r2) + 1];
+    }
+  for (int j = 0; j < m; ++j) cnt[(size_t)j + 1] += cnt[j];
+  std::vector<std::pair<int, double>> ent((size_t)nM);
+  {
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int k = 0; k < m; ++k)
+      for (long long e = P.Mp[k]; e < P.Mp[k + 1]; ++e) {
+        const int r1 = P.perm[P.Mi[e]], r2 = P.perm[k];
+        ent[(size_t)fill[std::min(r1, r2)]++] = {std::max(r1, r2), sval[(size_t)e]};
+      }
+  }
+  for (int j = 0; j < m; ++j) {
+    std::sort(ent.begin() + cnt[j], ent.begin() + cnt[(size_t)j + 1],
+              [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+    colptr[j] = cnt[j];
+  }
+  colptr[m] = cnt[m];
+  for (long long e = 0; e < nM; ++e) {
+    rowidx[e] = ent[(size_t)e].first;
+    vals[e] = ent[(size_t)e].second;
+  }
+  return HIPFACT_OK;
+}
+
+// ---------------------------------------------------------------------------
 int hipfact_spmat_create(hipfact_handle* h, int num_rows, int num_cols, const int* colptr, const int* rowidx,
                          const double* vals, hipfact_spmat** out) {
   int rc = enter(h);

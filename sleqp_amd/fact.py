@@ -142,6 +142,19 @@ class HipFact:
                                                      int(max_iter), _ptr(step), C.byref(dual), C.byref(its)))
         return step, dual.value, its.value
 
+    def reduced_matrix(self):
+        """hipfact_reduced_matrix: S = A_W A_W^T (sparse, lower CSC, working-set row order) from the device."""
+        import scipy.sparse as sp
+
+        nnz = C.c_int()
+        self._check(self._lib.hipfact_reduced_matrix(self._h, C.byref(nnz), None, None, None))
+        m = int(self.info("m"))
+        cp = np.empty(m + 1, dtype=np.int32)
+        ri = np.empty(max(nnz.value, 1), dtype=np.int32)
+        vx = np.empty(max(nnz.value, 1), dtype=np.float64)
+        self._check(self._lib.hipfact_reduced_matrix(self._h, C.byref(nnz), _ptr(cp), _ptr(ri), _ptr(vx)))
+        return sp.csc_matrix((vx[:nnz.value], ri[:nnz.value], cp), shape=(m, m))
+
     def tr_solve(self, hess, gradient, trust_radius: float, method: int = 1, stat_tol: float = 1e-6,
                  max_iter: int = 100):
         """hipfact_tr_solve: method 0 = projected Steihaug CG (tr/steihaug_solver.c), 1 = generalised Lanczos

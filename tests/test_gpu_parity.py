@@ -486,6 +486,29 @@ def test_pattern_lru_for_set_matrix(fact):
     assert fact.info("plan_swaps") >= 6
 
 
+def test_reduced_matrix_is_the_sparse_product(fact):
+    """S = A_W A_W^T from the device (product lists = symbolic SpGEMM, one fixed-order sum per
+    structural entry) against scipy, in working-set row order, sparse where reduced_aug_jac.c:323-377 is dense."""
+    from sleqp_amd.sparse import SleqpMat
+
+    for n, m, kind, frac in [(7, 3, "u", 0.3), (300, 150, "b", 0.1), (2000, 900, "u", 0.05)]:
+        J, vi, ci, W = _problem(n, m, kind, frac, 5)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        S = fact.reduced_matrix()
+        K = sp.csc_matrix((kd, kr, kc), shape=(N, N))
+        A = K[n:, :n].tocsr()
+        want = sp.tril(A @ A.T, format="csc")
+        want.sort_indices()
+        assert S.shape == (W, W) and np.all(np.diff(S.indptr) >= 1)
+        for j in range(W):  # rows strictly ascending per column, lower triangle (the SleqpMat invariants, mat.c:797-804)
+            rows = S.indices[S.indptr[j]:S.indptr[j + 1]]
+            assert np.all(np.diff(rows) > 0) and rows[0] == j
+        assert abs(S - want).max() <= 1e-13 * max(1.0, abs(want).max())
+        # structural entries only: as many as the product has (cancellation aside), far fewer than the dense triangle
+        assert S.nnz >= want.nnz and S.nnz <= W * (W + 1) // 2
+
+
 def test_determinism(fact):
     """Same inputs -> bitwise identical solution (fixed summation order, no atomics)."""
     from sleqp_amd.sparse import SleqpMat

@@ -40,6 +40,8 @@ def shim(hipfact_lib):
 def test_shim_exports_reference_entry_points(shim):
     for name in ["sleqp_fact_create_default", "sleqp_fact_hipfact_create", "sleqp_hipfact_aug_jac_create",
                  "sleqp_hipfact_tr_solver_create", "sleqp_hipfact_tr_bind", "sleqp_problem_hess_prod",
+                 "sleqp_hipfact_mat_create", "sleqp_hipfact_mat_set", "sleqp_hipfact_mat_mult_vec",
+                 "sleqp_hipfact_mat_mult_vec_trans", "sleqp_hipfact_mat_release",
                  "sleqp_hipfact_tr_set_hessian", "sleqp_tr_solver_solve", "sleqp_tr_solver_release",
                  "sleqp_fact_set_matrix", "sleqp_fact_solve", "sleqp_fact_solution", "sleqp_fact_cond",
                  "sleqp_fact_flags", "sleqp_fact_release"]:
@@ -430,6 +432,56 @@ def test_aug_jac_shim_skips_unchanged_working_set_for_linear_constraints(shim, h
         _tr_teardown(shim, settings, problem, iterate, aug)
 
 
+@pytest.mark.gpu
+def test_mat_shim_products_against_oracle(shim, hipfact_lib):
+    """shim/mat_hipfact.c: sleqp_mat_mult_vec / sleqp_mat_mult_vec_trans (sparse/mat.c:282-363) on the device,
+    including the reference's own known answer (sleqp_sparse_matrix_test.c:12-56) and the eps filter."""
+    import scipy.sparse as sp
+
+    import oracle
+
+    handle = C.c_void_p()
+    assert hipfact_lib.hipfact_create(C.byref(handle), 0) == 0
+    mat = C.c_void_p()
+    assert shim.sleqp_hipfact_mat_create(C.byref(mat), handle) == 0, shim.sleqp_error_msg()
+    rng = np.random.default_rng(3)
+    cases = [sp.csc_matrix(np.array([[1.0, 2.0, 0.0], [0.0, 3.0, 4.0]]))]  # the 2 x 3 matrix of the reference test
+    cases += [sp.random(r, c, density=d, random_state=2, format="csc") for r, c, d in ((40, 70, 0.1), (500, 300, 0.02))]
+    for M in cases:
+        M.sort_indices()
+        r, c = M.shape
+        H = _push_matrix(shim, M)
+        for rep in range(2):  # second round: same pattern, values-only update
+            assert shim.sleqp_hipfact_mat_set(mat, H) == 0, shim.sleqp_error_msg()
+            xi = np.sort(rng.choice(c, max(1, c // 2), replace=False))
+            xd = rng.standard_normal(xi.size)
+            if (r, c) == (2, 3):
+                xi, xd = np.arange(3), np.array([2.0, 4.0, 3.0])
+            x = _vec(shim, c, xi, xd)
+            out = np.zeros(r)
+            assert shim.sleqp_hipfact_mat_mult_vec(mat, x, out.ctypes.data_as(C.c_void_p)) == 0, shim.sleqp_error_msg()
+            want = oracle.mat_mult_vec(r, c, M.indptr, M.indices, M.data, xi, xd)
+            assert rel_err(out, want) <= 1e-14
+            if (r, c) == (2, 3):
+                assert np.allclose(out, [10.0, 24.0], atol=1e-8)
+            yi = np.sort(rng.choice(r, max(1, r // 2), replace=False))
+            yd = rng.standard_normal(yi.size)
+            y = _vec(shim, r, yi, yd)
+            res = C.POINTER(SleqpVecC)()
+            assert shim.sleqp_vec_create_empty(C.byref(res), c) == 0
+            eps = 0.05 if c > 3 else 0.0
+            assert shim.sleqp_hipfact_mat_mult_vec_trans(mat, y, C.c_double(eps), res) == 0, shim.sleqp_error_msg()
+            ti, td = oracle.mat_mult_vec_trans(r, c, M.indptr, M.indices, M.data, yi, yd, eps)
+            got_idx = [res.contents.indices[k] for k in range(res.contents.nnz)]
+            assert got_idx == list(ti)
+            assert rel_err(_dense(res), oracle.vec_to_raw(c, ti, td)) <= 1e-14
+            for v in (x, y, res):
+                shim.sleqp_vec_free(C.byref(v))
+        shim.sleqp_mat_release(C.byref(H))
+    assert shim.sleqp_hipfact_mat_release(C.byref(mat)) == 0 and not mat
+    assert hipfact_lib.hipfact_free(C.byref(handle)) == 0
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src/main"), reason="reference tree not present")
 def test_shim_compiles_against_the_reference_headers(tmp_path):
     """Boundary hygiene: the three shim files, WITHOUT HIPFACT_STANDALONE, type-check against the real
@@ -456,7 +508,7 @@ def test_shim_compiles_against_the_reference_headers(tmp_path):
         for name in os.listdir(os.path.join(ref, sub)):
             if name.startswith("pub_") and name.endswith(".h"):
                 os.symlink(os.path.join(ref, sub, name), inc / sub / name)
-    for src in ("fact_hipfact.c", "aug_jac_hipfact.c", "tr_hipfact.c"):
+    for src in ("fact_hipfact.c", "aug_jac_hipfact.c", "tr_hipfact.c", "mat_hipfact.c"):
         # the files live in src/main/{fact,aug_jac,tr}/ of a SLEQP checkout and include their neighbours by
         # bare name, like fact_lapack.c / standard_aug_jac.c / steihaug_solver.c do
         cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-I", str(tmp_path), "-I", str(inc), "-I", ref,
