@@ -7,7 +7,7 @@
  * (densified on the host like sleqp_vec_to_raw, sparse/vec.c:105-119) and one dense vector comes back, packed
  * with sleqp_vec_set_from_raw (sparse/vec.c:71-103) for the transposed product.
  *
- * Call sites (INTEGRATION.md section 8):
+ * Call sites (INTEGRATION.md section 7):
  *   newton.c:377      sleqp_mat_mult_vec_trans(cons_jac, violated_multipliers, zero_eps, sparse_cache)
  *   working_step.c:341, direction.c:66   sleqp_mat_mult_vec(cons_jac, direction, dense_cache)
  */
