@@ -110,6 +110,21 @@ def run():
     lib.hipfact_debug_trace_fine.argtypes = [C.c_void_p]
     assert lib.hipfact_debug_trace_fine(fine.ctypes.data_as(C.c_void_p)) == 0
     fine = fine.reshape(4096, 40)
+    # per level: when its first pivot workgroup got its children, when its last Schur workgroup published
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from plan_emul import Plan
+
+    P = Plan(lib, N, cp, ri, vx)
+    lev = P.sn_level
+    print("# per level of the dataflow launch (us): fronts, pivots waited (first..last), pivots done (last), panels published (last), Schur published (last)")
+    for l in range(int(f.info("factor_top_level")), P.nlevels):
+        m_ = lev[front] == l
+        pv, pn, sc = m_ & (role == 0), m_ & (role == 1), m_ & (role == 2)
+        def mx(a): return a.max() if a.size else float("nan")
+        def mn(a): return a.min() if a.size else float("nan")
+        w_ = tt[pv, 1]; w_ = w_[w_ > 0]
+        print(f"  level {l:2d}  fronts {int(pv.sum()):4d}  panel wgs {int(pn.sum()):4d}  schur wgs {int(sc.sum()):5d}  pivots start {mn(tt[pv, 0]):7.1f}  waited {mn(w_) if w_.size else 0:7.1f} .. {mx(w_) if w_.size else 0:7.1f}"
+              f"  pivots done {mx(tt[pv, 2]):7.1f}  panels published {mx(tt[pn, 3]):7.1f}  schur published {mx(tt[sc, 3]):7.1f}")
     names = ["pivot", "panel", "schur"]
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
