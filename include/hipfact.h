@@ -264,7 +264,12 @@ int hipfact_tridiag_tr(int k, const double* delta, const double* gamma, double g
  *              "wide_min_rows" (fronts with at least this many update rows
  *              are solved by several workgroups, 0 = off),
  *              "pull_max_children" (0 = extend-add through the separate
- *              assembly kernel), "top_prefetch", "split_max_fronts";
+ *              assembly kernel), "top_prefetch", "split_max_fronts",
+ *              "solve_fused" (0: the per-level / two-launch solve kernels on
+ *              the factor panels instead of the single launch on solve
+ *              panels), "spanel_fold" (0: the solve panels are built by a
+ *              launch of their own instead of by filler workgroups of the
+ *              dataflow launch; "spanel_fold_room": how many per level);
  *   "profile" (1: event-time every kernel class, read back with
  *              "prof_<class>_ms" / "prof_<class>_count"; -1 resets).
  * Unknown names return HIPFACT_EINVAL. */

@@ -32,18 +32,19 @@ def build():
     a = s.index("__global__ __launch_bounds__(512) void k_factor_top(")
     b = s.index("// titems: fronts of the levels >= top_level, children before parents")
     seg = s[a:b]
-    seg = seg.replace("  ChildWait cw;\n  cw.n = T.nwait;",
-                      "  TRW(0);\n  if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 7] = T.role * 100000 + T.front;\n"
-                      "  ChildWait cw;\n  cw.n = T.nwait;", 1)
+    seg = seg.replace("  const FrontItem& S = T.it;\n",
+                      "  const FrontItem& S = T.it;\n  TRW(0);\n  if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 7] = T.role * 100000 + T.front;\n", 1)
+    seg = seg.replace("    dev_build_solve_panel(sitems[S.part], L, SPf, SPb, lds);\n    return;",
+                      "    TRW(1);\n    dev_build_solve_panel(sitems[S.part], L, SPf, SPb, lds);\n    __syncthreads();\n    TRW(2);\n    return;", 1)
     seg = seg.replace("    flag_publish_add(&bdone[T.front]);", "    TRW(2);\n    flag_publish_add(&bdone[T.front]);\n    TRW(3);", 1)
     seg = seg.replace("    dev_panel_rows_product_posted(", "    TRW(1);\n    dev_panel_rows_product_posted(", 1)
     seg = seg.replace("    flag_publish_add(&cdone[T.front]);", "    TRW(2);\n    flag_publish_add(&cdone[T.front]);\n    TRW(3);", 1)
     seg = seg.replace("    flag_publish_add(&ddone[T.front]);", "    TRW(2);\n    flag_publish_add(&ddone[T.front]);\n    TRW(3);", 1)
     s = s[:a] + seg + s[b:]
-    s = s.replace("    cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited",
-                  "    if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
-                  "    cw.wait();\n"
-                  "    if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 1] = wall_clock64();", 1)
+    s = s.replace("      cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited",
+                  "      if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
+                  "      cw.wait();\n"
+                  "      if (threadIdx.x == 0 && cw.n > 0) g_trace[blockIdx.x * 8 + 1] = wall_clock64();", 1)
     s = s.replace("    flag_wait_ge(wait_addr, wait_target, info);\n  }\n  const int si = tid & 63;",
                   "    if (threadIdx.x == 0) g_trace[blockIdx.x * 8 + 5] = wall_clock64();\n"
                   "    flag_wait_ge(wait_addr, wait_target, info);\n"
@@ -51,8 +52,8 @@ def build():
     # pivot role detail: after the children gather, after the first diagonal block, after every step
     s = s.replace("__device__ long long g_trace[4096 * 8];", "__device__ long long g_trace[4096 * 8];\n__device__ long long g_piv[4096 * 24];\n"
                   "#define TRP(slot) if (threadIdx.x == 0) g_piv[blockIdx.x * 24 + (slot)] = wall_clock64()", 1)
-    s = s.replace("      __syncthreads();\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n      } else {\n        pivot_gather_stage2(pc, invb, wp, lane, wave, v);",
-                  "      __syncthreads();\n      TRP(0);\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n        TRP(1);\n      } else {\n        pivot_gather_stage2(pc, invb, wp, lane, wave, v);", 1)
+    s = s.replace("      __syncthreads();\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n      } else {\n#pragma unroll\n        for (int cc = 0; cc < 2; ++cc)",
+                  "      __syncthreads();\n      TRP(0);\n      if (wave == 0) {\n        if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);\n        TRP(1);\n      } else {\n#pragma unroll\n        for (int cc = 0; cc < 2; ++cc)", 1)
     s = s.replace("    __syncthreads();\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", "    __syncthreads();\n    TRP(2 + 2 * kb);\n    // S3 + look-ahead S1: tile t = 0 is the next diagonal block (kb+1, kb+1)", 1)
     s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n  }", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();\n    TRP(3 + 2 * kb);\n  }", 1)
     # finer: inside a step, wave 0 (next diagonal tile, diagonal block) and wave 1 (trailing tiles, inverse row)
@@ -62,8 +63,20 @@ def build():
                   "        if (!(phases & 64)) dev_trailing_tile(c, k0, kb + 1, kb + 1);\n        TRF(0, 4 * kb);\n        const long long cyc0 = __builtin_readcyclecounter();\n        if (!(phases & 32)) dev_diag_block(c, scratch, k0 + 16, info);\n        if (threadIdx.x == 0 && kb == 0) g_fine[blockIdx.x * 40 + 39] = __builtin_readcyclecounter() - cyc0;\n        TRF(0, 4 * kb + 1);", 1)
     s = s.replace("    if (ROWINV && wave == 1 + (kb + 3) % 7) {", "    TRF(1, 4 * kb + 2);\n    if (ROWINV && wave == 1 + (kb + 3) % 7) {", 1)
     s = s.replace("      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    __syncthreads();", "      xpend = x;\n      xrow = kb;\n      xcol = j;\n    }\n    TRF(1, 4 * kb + 3);\n    __syncthreads();", 1)
+    # anatomy of one diagonal block (the fourth of a front): shader clocks at entry, operands loaded, steps 0-7
+    # done, steps 8-14 done, results stored
+    s = s.replace("  double a[16], x[4];\n", "  double a[16], x[4];\n  const long long dcA = __builtin_readcyclecounter();\n", 1)
+    s = s.replace("  double dsel = a[0];  // pivot 0 (lane li = 0 keeps it)",
+                  "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n  const long long dcB = __builtin_readcyclecounter();\n  double dsel = a[0];  // pivot 0 (lane li = 0 keeps it)", 1)
+    s = s.replace("  nl = diag_step<7>(a, x, dsel, li, nl);\n", "  nl = diag_step<7>(a, x, dsel, li, nl);\n  const long long dcC = __builtin_readcyclecounter();\n", 1)
+    s = s.replace("  nl = diag_step<14>(a, x, dsel, li, nl);\n", "  nl = diag_step<14>(a, x, dsel, li, nl);\n  const long long dcD = __builtin_readcyclecounter();\n", 1)
+    s = s.replace("    if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);\n  }\n}",
+                  "    if (nneg) atomicAdd(&info[INFO_NEG_PIVOT], nneg);\n  }\n"
+                  "  if (threadIdx.x == 0 && k0 == 48) {\n    const long long dcE = __builtin_readcyclecounter();\n"
+                  "    long long* g = g_fine + blockIdx.x * 40 + 32;\n    g[0] = dcB - dcA;\n    g[1] = dcC - dcB;\n    g[2] = dcD - dcC;\n    g[3] = dcE - dcD;\n  }\n}", 1)
+    assert "dcE" in s and "dcC" in s and "dcB" in s and "dcA" in s
     assert s.count("TRF(") >= 5
-    assert s.count("TRP(") >= 5
+    assert "TRP(0)" in s and "TRP(1)" in s and s.count("g_trace[blockIdx.x * 8 + 1]") >= 2
     assert s.count("TRW(") >= 7
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "hipfact.hip")
@@ -125,20 +138,32 @@ def run():
         w_ = tt[pv, 1]; w_ = w_[w_ > 0]
         print(f"  level {l:2d}  fronts {int(pv.sum()):4d}  panel wgs {int(pn.sum()):4d}  schur wgs {int(sc.sum()):5d}  pivots start {mn(tt[pv, 0]):7.1f}  waited {mn(w_) if w_.size else 0:7.1f} .. {mx(w_) if w_.size else 0:7.1f}"
               f"  pivots done {mx(tt[pv, 2]):7.1f}  panels published {mx(tt[pn, 3]):7.1f}  schur published {mx(tt[sc, 3]):7.1f}")
-    names = ["pivot", "panel", "schur"]
+    names = ["pivot", "panel", "schur", "spanl"]
+    sp = role == 3
+    if sp.any():
+        # solve-panel items (role 3): stamped at start only (slot 0); their end is not on the record, so the window
+        # they run in is given by the starts
+        idx = np.nonzero(sp)[0]
+        print(f"# solve-panel items: {int(sp.sum())}, resident from {tt[sp, 0].min():.1f} .. {tt[sp, 0].max():.1f} us, finished {tt[sp, 2].min():.1f} .. {tt[sp, 2].max():.1f}, "
+              f"mean duration after their wait {np.mean(tt[sp, 2] - tt[sp, 1]):.1f} us; by position in the launch:")
+        for a in range(0, len(idx), max(1, len(idx) // 12)):
+            b = idx[a:a + max(1, len(idx) // 12)]
+            print(f"    items {b[0]:5d}..{b[-1]:5d}: resident {tt[b, 0].min():7.1f} .. {tt[b, 0].max():7.1f}  finished {tt[b, 2].min():7.1f} .. {tt[b, 2].max():7.1f}")
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
-    for i in range(max(0, n - 60), n):
+    crit = [i for i in range(n) if role[i] != 3]
+    for i in crit[-60:]:
         extra = ""
         print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {tt[i, 5]:8.2f}  waited {tt[i, 1]:8.2f}"
               f"  done {tt[i, 2]:8.2f}  published {tt[i, 3]:8.2f}{extra}")
-        if role[i] == 0 and i >= n - 16:
+        if role[i] == 0 and i >= crit[-16]:
             base = t[:, 0][t[:, 0] > 0].min()
             st = [(x - base) / 100.0 for x in piv[i] if x > 0]
             print("        pivot detail (gathered, first diagonal block, then per step: block column done, step done): "
                   + " ".join(f"{x:.2f}" for x in st))
             print("        shader-clock ticks of the diagonal block of step 0:", fine[i][39])
-            fs = [(x - base) / 100.0 for x in fine[i][:39] if x > 0]
+            print("        shader clocks of the fourth diagonal block: operands loaded, steps 0-7, steps 8-14, stored + checked:", list(fine[i][32:36]))
+            fs = [(x - base) / 100.0 for x in fine[i][:32] if x > 0]
             print("        per step: wave 0 next diagonal tile updated, diagonal block done; wave 1 trailing tiles done, inverse row done: "
                   + " ".join(f"{x:.2f}" for x in fs))
 

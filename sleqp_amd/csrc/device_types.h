@@ -60,6 +60,7 @@ struct TopFItem {
   int target;           // Schur: panel workgroups of the own front
   int crows;            // panel: rows per workgroup (128, or 64 with two waves per 16-row strip)
   int sidx, scount;     // Schur: index among / number of the Schur workgroups of the front
+  int post;             // the pivot workgroup posts inv(L11) tile by tile, the panel workgroups poll for it (no flag hop)
   long long xoff;       // the front's wp x wp slot in the arena of posted pivot blocks
 };
 

@@ -225,6 +225,9 @@ struct hipfact_handle : PlanState {
   int plan_cache_max = 4;
   bool spanel_side = false;       // solve panels of the bottom levels on a second stream beside k_factor_top (measured: no gain, the
                                   // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
+  bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
+  int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
+  bool sp_folded = false;         // (result of the plan upload)
   bool solve_fused = true;        // one launch for the whole solve tree on the solve panels (when every front qualifies)
   bool assemble_superset = true;  // hipfact_assemble_kkt analyses a superset structure of J instead of K itself
   bool jdev_valid = false;        // pattern of the Jacobian resident in d_jp / d_ji
@@ -261,6 +264,7 @@ struct hipfact_handle : PlanState {
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
+  int factor_top_post = 64;   // levels with at most this many fronts post the pivot block to polling panel workgroups
   int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
@@ -353,6 +357,12 @@ static int upload(hipfact_handle* h, DevBuf& buf, const std::vector<T>& v) {
   HCHECK(h, buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
   if (!v.empty()) HCHECK(h, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
   return HIPFACT_OK;
+}
+
+// LDS of the solve-panel builder (k_build_solve_panels / role 3 of k_factor_top): X | 1 / d | tiles | offsets
+static size_t solve_panel_lds(int wmax) {
+  const size_t wp = (size_t)((wmax + 15) & ~15);
+  return (wp * (wp + 1) + wp + 8 * 16 * 17 + wp + 1024) * sizeof(double);
 }
 
 static int upload_plan(hipfact_handle* h) {
@@ -639,7 +649,20 @@ static int upload_plan(hipfact_handle* h) {
       if (!(li.count <= h->factor_top_max && h->pull_max_children > 0 && mch <= MAXCH)) break;
       --lvl;
     }
+    h->sp_folded = false;
     if (P.nlevels - lvl >= 2 && h->factor_top_max > 0) {
+      // fused solve: will there be solve panels (same conditions as below), and are they built inside this launch?
+      size_t sp_lds_pre = 0;
+      bool fold = h->solve_fused && h->spanel_fold && ns > 0;
+      {
+        int wmax = 1;
+        for (int s2 = 0; s2 < ns; ++s2) {
+          fold = fold && sn[s2].r <= 1024 && sn[s2].w >= 1;
+          wmax = std::max(wmax, sn[s2].w);
+        }
+        sp_lds_pre = solve_panel_lds(wmax);
+        fold = fold && sp_lds_pre <= 160 * 1024;
+      }
       auto ntiles = [&](int s) {
         const long long u = sn[s].r - sn[s].w, nt = (u + 63) / 64;
         return nt * (nt + 1) / 2;
@@ -649,6 +672,7 @@ static int upload_plan(hipfact_handle* h) {
         return nt * (nt + 1) / 2;
       };
       std::vector<TopFItem> tf;
+      std::vector<size_t> level_end, panel_end;  // end of the items / of the pivot and panel items of each level in tf
       size_t lds = 0;
       // slots of the posted pivot blocks (wp x wp each), all sentinel between factorisations
       std::vector<long long> xoff(ns, 0);
@@ -687,6 +711,7 @@ static int upload_plan(hipfact_handle* h) {
             t.wait_cnt[k] = P.sn_level[ch] >= lvl ? (int)(h->levels[P.sn_level[ch]].count <= h->factor_top_fine ? ntiles32(ch) : (ntiles(ch) + 1) / 2) : 0;
           }
           t.crows = fine ? 64 : 128;
+          t.post = li.count <= h->factor_top_post;
           t.xoff = xoff[s];
           t.target = (sn[s].r - sn[s].w + t.crows - 1) / t.crows;
           return t;
@@ -710,6 +735,7 @@ static int upload_plan(hipfact_handle* h) {
           const int crows = fine ? 64 : 128;
           for (int b = 0; b < (u + crows - 1) / crows; ++b) tf.push_back(base(s, 1, b));
         }
+        panel_end.push_back(tf.size());
         for (int s : narrow_first) {
           const int u = sn[s].r - sn[s].w, nt = fine ? (u + 31) / 32 : (u + 63) / 64;  // fine: 32 x 32 tiles
           std::vector<int> tiles;
@@ -724,6 +750,65 @@ static int upload_plan(hipfact_handle* h) {
             tf.push_back(t);
           }
         }
+        level_end.push_back(tf.size());
+      }
+      if (fold) {
+        // Solve-panel items (role 3) dealt into the levels.  Workgroups are dispatched in index order and a
+        // waiting one keeps its CU, so the residents are always the lowest-indexed unfinished items.  The Schur
+        // items of a level cannot start before its pivot and panel items are through (~30 us): solve-panel items
+        // (~20 us each) go between the panel and the Schur items of the level, as many as fit beside its pivot and
+        // panel items - they run on CUs that the Schur items would only have occupied waiting.
+        // Fronts in level order: those below the launch are final already, a front of the launch can follow the
+        // panel items of a later level (or wait a moment for its own).  What is left goes behind the root.
+        std::vector<TopFItem> out;
+        out.reserve(tf.size() + ns);
+        int qnext = 0;
+        auto filler = [&](int q) {
+          const int s = P.level_sn[q];
+          TopFItem t;
+          memset(&t, 0, sizeof(t));
+          t.it.Loff = sn[s].Loff;
+          t.it.w = sn[s].w;
+          t.it.r = sn[s].r;
+          t.it.part = q;  // index of the front's SolveItem (level order)
+          t.role = 3;
+          t.front = s;
+          t.part2 = -1;
+          if (P.sn_level[s] >= lvl) {
+            const int crows = h->levels[P.sn_level[s]].count <= h->factor_top_fine ? 64 : 128;
+            t.nwait = 1;
+            t.target = (sn[s].r - sn[s].w + crows - 1) / crows;
+          }
+          return t;
+        };
+        // a front of the launch without update rows (the root) writes its solve panel in its pivot item
+        std::vector<char> own(ns, 0);
+        std::vector<int> pos(ns, 0);
+        for (int q = 0; q < ns; ++q) pos[P.level_sn[q]] = q;
+        for (TopFItem& t : tf)
+          if (t.role == 0 && t.it.r == t.it.w) {
+            t.sidx = pos[t.front] + 1;
+            own[t.front] = 1;
+          }
+        auto skip_own = [&] {
+          while (qnext < ns && own[P.level_sn[qnext]]) ++qnext;
+        };
+        size_t from = 0;
+        for (int l = lvl; l < P.nlevels; ++l) {
+          const size_t mid = panel_end[l - lvl], to = level_end[l - lvl];
+          out.insert(out.end(), tf.begin() + from, tf.begin() + mid);
+          long long room = (long long)h->spanel_fold_room - (long long)(mid - from);
+          for (skip_own(); room > 0 && qnext < ns && P.sn_level[P.level_sn[qnext]] <= l; skip_own()) {
+            out.push_back(filler(qnext++));
+            --room;
+          }
+          out.insert(out.end(), tf.begin() + mid, tf.begin() + to);
+          from = to;
+        }
+        for (skip_own(); qnext < ns; skip_own()) out.push_back(filler(qnext++));
+        tf.swap(out);
+        lds = std::max(lds, sp_lds_pre);
+        h->sp_folded = true;
       }
       h->ftop_level = lvl;
       h->ftop_count = (int)tf.size();
@@ -875,10 +960,7 @@ static int upload_plan(hipfact_handle* h) {
         wmax = std::max(wmax, T.w);
         si.push_back(T);
       }
-      {
-        const size_t wp = (size_t)((wmax + 15) & ~15);
-        h->sp_lds = (wp * (wp + 1) + wp + 8 * 16 * 17 + wp + 1024) * sizeof(double);  // X | 1 / d | tiles | offsets
-      }
+      h->sp_lds = solve_panel_lds(wmax);
       if (h->sp_lds <= 160 * 1024) {
         if ((rc = upload(h, h->d_sitems, si))) return rc;
         if ((rc = upload(h, h->d_sxuoff, xuoff))) return rc;
@@ -894,6 +976,10 @@ static int upload_plan(hipfact_handle* h) {
         h->fused_solve = true;
         h->sp_bytes = (double)(spf + spb) * sizeof(double);
       }
+    }
+    if (h->sp_folded && !h->fused_solve) {
+      h->error = "solve-panel items without solve panels";
+      return HIPFACT_EINTERNAL;
     }
   }
   // Capacity limits of the LDS-resident working sets (documented in INTEGRATION.md).  Only what can actually
@@ -1079,9 +1165,11 @@ static int factor_enqueue(hipfact_handle* h) {
     int* fl = reinterpret_cast<int*>(h->d_L.as<double>() + P.L_size);  // cleared with the L arena
     LAUNCH(PC_FACTOR_T, k_factor_top, dim3(h->ftop_count), dim3(512), h->ftop_lds, h->d_tfitems.as<TopFItem>(),
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
-           fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>());
+           fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>(),
+           h->sp_folded ? h->d_sitems.as<SolveItem>() : nullptr, h->sp_folded ? h->d_SPf.as<double>() : nullptr,
+           h->sp_folded ? h->d_SPb.as<double>() : nullptr);
   }
-  if (h->fused_solve && !h->no_dataflow) {
+  if (h->fused_solve && !h->no_dataflow && !(h->sp_folded && lsplit < P.nlevels)) {
     if (sp_done > 0) HCHECK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     if (P.nsuper > sp_done)
       LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper - sp_done), dim3(SPB), h->sp_lds,
@@ -1584,6 +1672,9 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_WIDE_MIN")) h->wide_min_rows = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_TOP")) h->factor_top_max = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
+  if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
+  if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_SPANEL_ROOM")) h->spanel_fold_room = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
   if (const char* s = getenv("HIPFACT_GRAPH")) h->use_graph = atoi(s) != 0;
@@ -2645,6 +2736,16 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->fake_timeouts = (int)value;
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "spanel_fold")) {  // 0: the solve panels in a launch of their own behind the factorisation
+    if (h->spanel_fold != (value != 0.0)) invalidate_plans(h);
+    h->spanel_fold = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "spanel_fold_room")) {
+    if (h->spanel_fold_room != (int)value) invalidate_plans(h);
+    h->spanel_fold_room = (int)value;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "spanel_side")) {
     h->spanel_side = value != 0.0;
     drop_graphs(h);
@@ -2752,7 +2853,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

@@ -376,6 +376,7 @@ __device__ __forceinline__ void fmac_rowb_f64(double& acc, double src, double mu
 // their part of a is never read again (row k was broadcast in this very step, the pivots are
 // captured when they become final), so the a updates take the raw multiplier and the select
 // stays off the dependent chain.
+#ifndef HIPFACT_DIAG_INTERLEAVED
 template <int K>
 __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], double& dsel, int li, double nl) {
   double nl_next = 0.0;
@@ -397,15 +398,89 @@ __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], dou
   return nl_next;
 }
 
+#else
+// The wave issues in order, and every instruction of the pivot chain (update of the next pivot -> broadcast ->
+// reciprocal -> cubic correction, three FMAs -> multiplier) waits for its predecessor.  Left to the compiler the
+// chain ends up in one piece behind the row updates of the step (212 clocks per pivot: chain + updates); here
+// the updates of the step (a[K+2..15], then the slices of x) are dealt between the chain instructions, so that
+// they issue in the shadow of its latencies.  Everything is volatile assembly, i.e. stays in this order; the
+// reciprocal sequence is that of fast_rcp, operation by operation (same bits).  Hazards the recogniser cannot
+// see inside assembly: a DPP source needs two wait states after its producer (the chain's broadcast carries an
+// s_nop, the updates read registers of the previous step), a transcendental result one before its use.
+template <int K, int IDX>
+__device__ __forceinline__ void diag_bulk(double (&a)[16], double (&x)[4], double nl, double nlx) {
+  constexpr int NA = (K < 14) ? 14 - K : 0;  // a[K+2 .. 15]; columns j <= k are dead
+  if constexpr (IDX < NA) {
+    fmac_rowb_f64<K>(a[K + 2 + IDX], a[K + 2 + IDX], nl);
+  } else if constexpr (IDX - NA < 4 && 4 * (IDX - NA) <= K) {
+    // (a slice of x that is touched for the first time was initialised by compiler-generated vector code, and
+    // nlx is selected by it as well: two wait states, once per step)
+    if constexpr (IDX == NA) asm volatile("s_nop 1");
+    fmac_rowb_f64<K>(x[IDX - NA], x[IDX - NA], nlx);
+  }
+}
+template <int K>
+__device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], double& dsel, int li, double nl) {
+  double nl_next = 0.0;
+  const double nlx = (li > K) ? nl : 0.0;  // rows i <= k of x are finished
+  if (K < 15) fmac_rowb_f64<K>(a[K + 1], a[K + 1], nl);
+  diag_bulk<K, 0>(a, x, nl, nlx);
+  if constexpr (K < 14) {
+    double d, x0, e, t, rc;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(d)
+                 : "v"(a[K + 1]), "n"(K + 1));
+    diag_bulk<K, 1>(a, x, nl, nlx);
+    asm volatile("v_rcp_f64 %0, %1" : "=v"(x0) : "v"(d));
+    diag_bulk<K, 2>(a, x, nl, nlx);
+    diag_bulk<K, 3>(a, x, nl, nlx);
+    diag_bulk<K, 4>(a, x, nl, nlx);
+    asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(d), "v"(x0));
+    diag_bulk<K, 5>(a, x, nl, nlx);
+    diag_bulk<K, 6>(a, x, nl, nlx);
+    asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(t) : "v"(e));
+    diag_bulk<K, 7>(a, x, nl, nlx);
+    diag_bulk<K, 8>(a, x, nl, nlx);
+    asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(rc) : "v"(x0), "v"(t));
+    diag_bulk<K, 9>(a, x, nl, nlx);
+    diag_bulk<K, 10>(a, x, nl, nlx);
+    asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(nl_next) : "v"(a[K + 1]), "v"(rc));
+    diag_bulk<K, 11>(a, x, nl, nlx);
+    diag_bulk<K, 12>(a, x, nl, nlx);
+    diag_bulk<K, 13>(a, x, nl, nlx);
+    diag_bulk<K, 14>(a, x, nl, nlx);
+    diag_bulk<K, 15>(a, x, nl, nlx);
+    diag_bulk<K, 16>(a, x, nl, nlx);
+    diag_bulk<K, 17>(a, x, nl, nlx);
+  } else {
+    diag_bulk<K, 1>(a, x, nl, nlx);
+    diag_bulk<K, 2>(a, x, nl, nlx);
+    diag_bulk<K, 3>(a, x, nl, nlx);
+    diag_bulk<K, 4>(a, x, nl, nlx);
+  }
+  dsel = (li == K + 1) ? a[K + 1] : dsel;  // pivot k + 1 is final since the first instruction of the step
+  return nl_next;
+}
+#endif
+
 __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int lda = c.lda;
   double* A = c.A;
   double a[16], x[4];
+  // full symmetric row from the stored lower triangle.  ONE load per element: two loads under a ternary are not
+  // speculated and a selected index a * lda + b is not if-converted either - both become sixteen exec-mask
+  // branches around a quarter-rate 64-bit multiply-add (900 of the 3400 clocks of a diagonal block,
+  // scripts/timeline.py).
+  // Element j of row li lives at (li, j) for j <= li and at (j, li) beyond: a walk along the row up to the diagonal
+  // and down the column from there, i.e. a running index with a selected increment (no multiply, no branch).
+  int at = (k0 + li) + k0 * lda;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)  // full symmetric row from the stored lower triangle
-    a[j] = (li >= j) ? A[(k0 + li) + (k0 + j) * lda] : A[(k0 + j) + (k0 + li) * lda];
+  for (int j = 0; j < 16; ++j) {
+    a[j] = A[at];
+    at += (j < li) ? lda : 1;
+  }
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) x[cc] = (li == 4 * cc + lk) ? 1.0 : 0.0;
   // The dependent chain of the whole front runs through these steps (pivot -> reciprocal ->
@@ -501,6 +576,23 @@ __device__ __forceinline__ void pivot_gather_stage1(const PullCtx& pc, const int
       }
     }
 }
+// The same gathers in two halves for the children that are awaited (k_factor_top): everything up to the
+// offsets inside the children's update matrices (maps, index arithmetic; they fit 32 bits: uc <= 2^15) happens
+// BEFORE the wait, so that behind it only the loads themselves remain - all of them in flight at once.
+__device__ __forceinline__ void pivot_offsets_stage1(const PullCtx& pc, const int* invb, int wp, int i1, int kq1,
+                                                     int (&o1)[MAXCH][4]) {
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    const int* ib = invb + ch * wp;
+    const int uc = pc.uc[ch];
+    const int ci = (ch < pc.n && i1 < wp) ? ib[i1] : -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ck = (ch < pc.n) ? ib[kq1 + 4 * q] : -1;
+      o1[ch][q] = (ci >= 0 && ck >= 0 && ci >= ck) ? ci + ck * uc : -1;
+    }
+  }
+}
 // Stage 2 of the pivot-block load (waves 1..7): the lower triangle of the columns 16 .. wp-1 only.
 // Column 16 + p is folded with column wp - 1 - p, so that every pair holds wp - 15 entries: slot
 // (s, j) of a thread is entry t = lane + 64 s of pair p = (wave - 1) + 7 j.
@@ -515,12 +607,12 @@ __device__ __forceinline__ bool stage2_elem(int wp, int wave, int lane, int s, i
   i = first ? ka + t : kb + (t - len1);
   return wave >= 1 && p < npairs && t < wp - 15;
 }
-__device__ __forceinline__ void pivot_gather_stage2(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
-                                                    double (&v)[2][8]) {
+__device__ __forceinline__ void pivot_gather_stage2_from(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
+                                                         double (&v)[2][8], int cfirst) {
   // two children in flight at a time, added in child order
 #pragma unroll
   for (int c0 = 0; c0 < MAXCH; c0 += 2)
-    if (c0 < pc.n) {
+    if (c0 >= cfirst && c0 < pc.n) {
       double g[2][2][8];
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
@@ -549,6 +641,30 @@ __device__ __forceinline__ void pivot_gather_stage2(const PullCtx& pc, const int
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[s2][j] += g[cc][s2][j];
     }
+}
+__device__ __forceinline__ void pivot_gather_stage2(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
+                                                    double (&v)[2][8]) {
+  pivot_gather_stage2_from(pc, invb, wp, lane, wave, v, 0);
+}
+// offsets of the first two children (the others, rare, go the ordinary way behind them)
+__device__ __forceinline__ void pivot_offsets_stage2(const PullCtx& pc, const int* invb, int wp, int lane, int wave,
+                                                     int (&o2)[2][2][8]) {
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const bool has = cc < pc.n;
+    const int uc = pc.uc[cc];
+    const int* ib = invb + cc * wp;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int i, k;
+        const bool valid = stage2_elem(wp, wave, lane, s2, j, i, k);
+        const int ci = (valid && has) ? ib[i] : -1;
+        const int ck = (valid && has) ? ib[k] : -1;
+        o2[cc][s2][j] = (ci >= 0 && ck >= 0) ? ci + ck * uc : -1;
+      }
+  }
 }
 
 // Dependencies of a workgroup of the single-launch top-of-tree factorisation (k_factor_top): the
@@ -644,9 +760,38 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < pc.n && tid < wp) invb[ch * wp + tid] = iv[ch];
     __syncthreads();
-    cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited
-    pivot_gather_stage1(pc, invb, wp, i1, kq1, v1);
-    if (!CHAIN || pc.next < 0) {
+    if constexpr (!CHAIN) {
+      // offsets first, then the wait, then nothing but loads: stage 1 of every child and stage 2 of the first
+      // two children leave together, one memory round trip for the lot (the update matrices were written on
+      // other XCDs moments ago: a round trip is ~1.5 us, and the index arithmetic of stage 2, ~25 instructions
+      // per entry, used to sit between the two)
+      int o1[MAXCH][4], o2[2][2][8];
+      pivot_offsets_stage1(pc, invb, wp, i1, kq1, o1);
+      if (wave >= 1) pivot_offsets_stage2(pc, invb, wp, lane, wave, o2);
+      cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited
+      double g1[MAXCH][4], g2[2][2][8];
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch)
+        if (ch < pc.n) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g1[ch][q] = pc.Uc[ch][o1[ch][q] >= 0 ? o1[ch][q] : 0];
+        }
+      if (wave >= 1) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+          if (cc < pc.n) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) g2[cc][s2][j] = pc.Uc[cc][o2[cc][s2][j] >= 0 ? o2[cc][s2][j] : 0];
+          }
+      }
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch)
+        if (ch < pc.n) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v1[q] += o1[ch][q] >= 0 ? g1[ch][q] : 0.0;
+        }
       if (i1 < wp) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
@@ -655,7 +800,15 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       if (wave == 0) {
         if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);
       } else {
-        pivot_gather_stage2(pc, invb, wp, lane, wave, v);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+          if (cc < pc.n) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[s2][j] += o2[cc][s2][j] >= 0 ? g2[cc][s2][j] : 0.0;
+          }
+        if (pc.n > 2) pivot_gather_stage2_from(pc, invb, wp, lane, wave, v, 2);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -666,8 +819,10 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       }
       __syncthreads();
     } else {
-      // more than MAXCH children: block after block (child order), everything gathered before
-      // anything is stored; the first diagonal block does not overlap the gather here
+      cw.wait();
+      pivot_gather_stage1(pc, invb, wp, i1, kq1, v1);
+      // levels with fronts of more than MAXCH children: block after block (child order), everything gathered
+      // before anything is stored; the first diagonal block does not overlap the gather here
       if (wave >= 1) pivot_gather_stage2(pc, invb, wp, lane, wave, v);
       for (int nx = pc.next; nx >= 0;) {
         const PullCtx px = make_pull(pm.more[nx], pm.U, pm.inv, pm.rel, 1);
@@ -770,7 +925,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         // remaining tiles over the other waves (over all waves when there is only one)
         // wave 0 carries the sequential chain; with eight waves, wave 4 shares its SIMD (and the
         // fp64 pipe that the MFMAs of a trailing tile keep busy), so it takes no tiles either
-        const bool quiet4 = (nw == 8);
+        const bool quiet4 = false;  // EXPERIMENT
         const int widx = quiet4 ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;
         const int first = (nw > 1) ? 1 + widx : 1;
         const int step = (nw > 1) ? (quiet4 ? 6 : nw - 1) : 1;
@@ -2115,21 +2270,52 @@ __device__ __forceinline__ void flag_publish_add(int* __restrict__ addr) {
   }
 }
 
-// LDS: the largest of the three roles (pivot: dd | A | Y | scratch | maps; panel: dd | X | maps;
-// Schur: dd | two teams of {SI, SJ, maps})
+// Role 3 (fused solve): the solve panels S = [X; -L21 X] of one front, ANY front of the tree.  The launch is bound
+// by the critical path of the tree; from the level on where a level's workgroups no longer fill the chip, the
+// host deals these items between the levels, as many as leave room for the level and its successor - they
+// run on CUs that would otherwise idle (3.7 GFLOP of fp64 MFMA work for the whole tree, ~100 us as a launch of
+// its own behind this one).  Fronts of this launch wait for their pivot and panel workgroups, all others were
+// finished before the launch.
+__device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const double* __restrict__ L,
+                                                      double* __restrict__ SPf, double* __restrict__ SPb, double* lds);
+
+// LDS: the largest of the roles (pivot: dd | A | Y | scratch | maps; panel: dd | X | maps;
+// Schur: dd | two teams of {SI, SJ, maps}; solve panels: X | 1 / d | tiles | offsets)
 __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__ items, double* __restrict__ L,
                                                    double* __restrict__ U, int* __restrict__ info,
                                                    const int* __restrict__ inv, const int* __restrict__ rel,
                                                    int* __restrict__ bdone, int* __restrict__ cdone,
-                                                   int* __restrict__ ddone, double* __restrict__ xarena) {
+                                                   int* __restrict__ ddone, double* __restrict__ xarena,
+                                                   const SolveItem* __restrict__ sitems, double* __restrict__ SPf,
+                                                   double* __restrict__ SPb) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TopFItem& T = items[blockIdx.x];
   const FrontItem& S = T.it;
+  if (T.role == 3) {
+    if (T.nwait) {  // a front of this launch: pivot block and every panel workgroup
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&bdone[T.front], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1 ||
+               __hip_atomic_load(&cdone[T.front], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T.target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 22)) {
+            atomicAdd(&info[INFO_TIMEOUT], 1);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    dev_build_solve_panel(sitems[S.part], L, SPf, SPb, lds);
+    return;
+  }
   FrontCtx c = make_ctx(S, L, U, lds);
-  // Levels with a handful of fronts (the latency-bound top of the tree) post the pivot block tile
-  // by tile for their panel workgroups; on wider levels hundreds of polling workgroups would
-  // flood the memory system for no gain (those levels are bound by occupancy), so they keep the flag.
-  c.Xa = (T.crows == 64) ? xarena + T.xoff : nullptr;
+  // Levels that are bound by latency (fewer workgroups than CUs) post the pivot block tile by tile for
+  // their panel workgroups; on wider levels hundreds of polling workgroups would flood the memory
+  // system for no gain (those levels are bound by occupancy), so they keep the flag.
+  c.Xa = T.post ? xarena + T.xoff : nullptr;
   const PullCtx pc = make_pull(S.pd, U, inv, rel, 1);
   ChildWait cw;
   cw.n = T.nwait;
@@ -2144,6 +2330,25 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
   if (T.role == 0) {
     dev_pivot_block<true>(c, info, 15, pc, cw);  // waits for the children between its prefetch and its gathers
     flag_publish_add(&bdone[T.front]);
+    // A front without update rows (the root): its solve panel is X and the pivots, both still in LDS - written here
+    // instead of by an item of its own that could only start now (same expressions, same bits)
+    if (T.sidx > 0) {
+      const SolveItem& Q = sitems[T.sidx - 1];
+      const int w = c.w, r = c.r, lda = c.lda;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const long long TSf = (long long)r * Q.Qf, TSb = (long long)w * Q.Pb;
+      double* __restrict__ sf = SPf + Q.spf;
+      double* __restrict__ sb = SPb + Q.spb;
+      for (int k = wave; k < w; k += 8) {
+        const long long of = (long long)(k / Q.Qf) * TSf + (long long)(k % Q.Qf) * r;
+        for (int i = k + lane; i < w; i += 64) sf[of + i] = (i == k) ? 1.0 : c.A[i + k * lda];
+      }
+      for (int i = wave; i < w; i += 8) {
+        const double di = 1.0 / c.dd[i];
+        const long long ob = (long long)(i / Q.Pb) * TSb + (long long)(i % Q.Pb) * w;
+        for (int k = lane; k <= i; k += 64) sb[ob + k] = ((i == k) ? 1.0 : c.A[i + k * lda]) * di;
+      }
+    }
   } else if (T.role == 1) {
     // panel rows incl. the children's contributions first (the children finished long ago),
     // then the pivot workgroup of the own front is awaited and only inv(L11) remains to be read
@@ -2661,11 +2866,8 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
 // accumulators.  Padding entries of the arenas and the zeros above the diagonal of X are zero from
 // the upload of the plan and never written.
 constexpr int SPB = 512;
-__global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __restrict__ items,
-                                                            const double* __restrict__ L, double* __restrict__ SPf,
-                                                            double* __restrict__ SPb) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const SolveItem& T = items[blockIdx.x];
+__device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const double* __restrict__ L,
+                                                      double* __restrict__ SPf, double* __restrict__ SPb, double* lds) {
   const int w = T.w, r = T.r, u = r - w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -2779,6 +2981,12 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
     const double di = dinv[i];
     for (int k = lane; k <= i; k += 64) sb[offB[i] + k] = X[i + k * ldx] * di;
   }
+}
+__global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __restrict__ items,
+                                                            const double* __restrict__ L, double* __restrict__ SPf,
+                                                            double* __restrict__ SPb) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  dev_build_solve_panel(items[blockIdx.x], L, SPf, SPb, lds);
 }
 
 // ---------------------------------------------------------------------------

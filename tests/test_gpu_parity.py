@@ -639,6 +639,45 @@ def test_top_of_tree_solve_variants_agree_bitwise(fact):
     assert rel_err(fused[0], outs[0]) <= 1e-11 and scaled_residual(K, fused[0], b) <= 1e-9
 
 
+def test_solve_panels_built_inside_the_top_of_tree_launch(fact):
+    """The solve panels S = [X; -L21 X] are built by filler items of the single-launch top-of-tree
+    factorisation (role 3 of k_factor_top; the root writes its own from LDS) instead of by a launch of
+    their own behind it.  Same arithmetic either way: the fused solve on them must give the same bits,
+    for fronts below the launch, fronts inside it (which wait for their pivot and panel workgroups)
+    and the root, over repeated factorisations (the counters they wait on are cleared per factorisation)."""
+    from sleqp_amd.sparse import SleqpMat
+
+    for kind, n, m, opts in [("b", 20000, 10000, {}), ("b", 20000, 10000, {"spanel_fold_room": 8}), ("u", 3000, 1500, {})]:
+        J, vi, ci, _ = _problem(n, m, kind, 0.0, 11)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        rng = np.random.default_rng(2)
+        rhs = [rng.standard_normal(N) for _ in range(2)]
+        outs = {}
+        for fold in (1, 0):
+            fact.set_option("refine_steps", 0)
+            fact.set_option("solve_fused", 1)
+            fact.set_option("spanel_fold", fold)
+            fact.set_option("spanel_fold_room", opts.get("spanel_fold_room", 224))
+            res = []
+            for rep in range(2):
+                fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+                assert fact.info("fused_solve") == 1.0
+                if fact.info("factor_top_count") > 0:
+                    assert fact.info("spanel_folded") == float(fold)
+                for b in rhs:
+                    fact.solve(b)
+                    res.append(fact.solution_raw(0, N))
+                assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
+            outs[fold] = res
+        for a, b_ in zip(outs[1], outs[0]):
+            assert np.array_equal(a, b_)
+        assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-9
+    fact.set_option("spanel_fold", 1)
+    fact.set_option("spanel_fold_room", 224)
+    fact.set_option("refine_steps", 1)
+
+
 def test_solve_sequence_with_changing_right_hand_sides(fact):
     """The single-launch solve sweeps exchange vectors element by element through slots that the
     opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
