@@ -652,6 +652,16 @@ def main():
                                "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                                "flops_per_step": flops, "avg_launch_us": prof[dom]["avg_launch_us"],
                                "note": "all factor flops attributed to the Schur kernel (upper bound)"}
+        if dom == "factorT" and fact.info("spanel_folded"):
+            # the launch also builds the solve panels of EVERY front (filler workgroups between its levels): reads each
+            # factor panel once more, writes both thread-major copies.  Not part of SURVEY 8(d)'s factor bytes, hence
+            # not in `achieved`; reported beside it.
+            extra = 8 * (fact.info("ent_fused") + fact.info("ent_split")) + fact.info("solve_panel_bytes")
+            out["roofline"]["fused_solve_panels"] = {
+                "bytes_per_launch": extra, "achieved_incl_GBps": (bytes_per_launch + extra) / avg_s / 1e9,
+                "frac_incl": (bytes_per_launch + extra) / avg_s / 1e9 / HBM_PEAK_GBS,
+                "note": "solve panels S = [X; -L21 X] of all fronts are built inside this launch (3.7 GFLOP fp64 MFMA); "
+                        "with spanel_fold=0 they are a launch of their own (k_build_solve_panels, ~98 us) and this one is ~35 us shorter"}
         fact.free()
         if world == 1 and not args.no_extras:
             out["boundary"] = boundary_bench(J, N, cp, ri, vx, b, 30, local_rank)

@@ -225,6 +225,7 @@ struct hipfact_handle : PlanState {
   int plan_cache_max = 4;
   bool spanel_side = false;       // solve panels of the bottom levels on a second stream beside k_factor_top (measured: no gain, the
                                   // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
+  bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
   bool sp_folded = false;         // (result of the plan upload)
@@ -1272,14 +1273,14 @@ static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
 
 // M y = t on the device (y in: t in pivot order, out: solution); skip: device flag that turns
 // every launch into a no-op (correction passes of a solve that has already converged)
-static void solve_m_async(hipfact_handle* h, const int* skip) {
+static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs = nullptr) {
   const Plan& P = h->plan;
   if (h->fused_solve && !h->no_dataflow) {
     LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
            h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
            h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_xhat.as<double>(), h->d_uvec.as<double>(), h->d_ysol.as<double>(), P.m, h->d_epoch.as<int>(),
-           h->d_info.as<int>(), skip);
+           h->d_info.as<int>(), skip, rhs ? *rhs : RhsIn{nullptr, nullptr, nullptr, nullptr, SaddleMaps{nullptr, nullptr, nullptr, 0}, nullptr});
     return;
   }
   const int ltop = h->no_dataflow ? P.nlevels : std::min(h->top_level, P.nlevels);
@@ -1319,9 +1320,15 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
   if (P.saddle) {
     const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
-      LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks((long long)P.m * 16)), dim3(FB), 0, P.m, h->d_Ar_ptr.as<int>(),
-             h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b, h->d_y.as<double>(), skip);
-      solve_m_async(h, skip);
+      if (h->fused_solve && !h->no_dataflow && h->rhs_fused) {
+        // the forward items of the single launch form their own rows of the right-hand side
+        const RhsIn R{h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b};
+        solve_m_async(h, skip, &R);
+      } else {
+        LAUNCH(PC_RHS, k_rhs_saddle, dim3(nblocks((long long)P.m * 16)), dim3(FB), 0, P.m, h->d_Ar_ptr.as<int>(),
+               h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b, h->d_y.as<double>(), skip);
+        solve_m_async(h, skip);
+      }
     }
     if (acc)
       LAUNCH(PC_XUPD, k_x_saddle<true>, dim3(nblocks((long long)P.n * 8)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
@@ -1674,6 +1681,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SPANEL_ROOM")) h->spanel_fold_room = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
@@ -2734,6 +2742,11 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "debug_fake_timeout")) {  // test hook for the fallback to the per-level launches
     h->fake_timeouts = (int)value;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "rhs_fused")) {  // 0: k_rhs_saddle in front of the single-launch solve
+    if (h->rhs_fused != (value != 0.0)) drop_graphs(h);
+    h->rhs_fused = value != 0.0;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "spanel_fold")) {  // 0: the solve panels in a launch of their own behind the factorisation

@@ -925,7 +925,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         // remaining tiles over the other waves (over all waves when there is only one)
         // wave 0 carries the sequential chain; with eight waves, wave 4 shares its SIMD (and the
         // fp64 pipe that the MFMAs of a trailing tile keep busy), so it takes no tiles either
-        const bool quiet4 = false;  // EXPERIMENT
+        const bool quiet4 = (nw == 8);
         const int widx = quiet4 ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;
         const int first = (nw > 1) ? 1 + widx : 1;
         const int step = (nw > 1) ? (quiet4 ? 6 : nw - 1) : 1;
@@ -2727,13 +2727,53 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
 // so it must never find the previous solve's value - the copy of the previous launch is put back to
 // the sentinel by the forward items while this launch exchanges through the other one.
 // ---------------------------------------------------------------------------
+// (working-set maps and equilibration of the saddle-point front end: described with the saddle kernels below)
+struct SaddleMaps {
+  const int* __restrict__ vmap;
+  const int* __restrict__ cmap;
+  const double* __restrict__ dscale;  // per pivot position
+  int n;
+};
+__device__ __forceinline__ int ext_row(const SaddleMaps& M, int s) { return M.cmap ? M.cmap[s] : M.n + s; }
+constexpr int RL = 16;  // lanes per row of A^_p in the right-hand side product
+// what the forward items of the single-launch solve need to form their own rows of t = A^_p b~_x - D b_y[perm]
+// (Ar_ptr null: t was left in y by a launch in front)
+struct RhsIn {
+  const int* __restrict__ Ar_ptr;
+  const int* __restrict__ Ar_col;
+  const double* __restrict__ Ar_val;
+  const int* __restrict__ perm;
+  SaddleMaps M;
+  const double* __restrict__ b;
+};
+// one row of t, RL lanes per row (k_rhs_saddle and the forward items: same partial sums, same shuffle tree, same bits)
+__device__ __forceinline__ double rhs_row(const RhsIn& R, int k, int sub) {
+  double s = 0.0;
+  const int p1 = R.Ar_ptr[k + 1];
+  if (R.M.vmap) {
+    for (int p = R.Ar_ptr[k] + sub; p < p1; p += RL) {
+      const int j = R.Ar_col[p], v = R.M.vmap[j];
+      s += R.Ar_val[p] * R.b[v >= 0 ? v : j];
+    }
+  } else {
+    for (int p = R.Ar_ptr[k] + sub; p < p1; p += RL) s += R.Ar_val[p] * R.b[R.Ar_col[p]];
+  }
+#pragma unroll
+  for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
+  if (sub == 0) {
+    const int i = ext_row(R.M, R.perm[k]);
+    s = i >= 0 ? s - R.b[i] * R.M.dscale[k] : 0.0;
+  }
+  return s;
+}
 constexpr int ST = 1024;  // threads per workgroup
 
 __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* __restrict__ SPf,
                                               const long long* __restrict__ xuoff, const int* __restrict__ xinvoff,
                                               const int* __restrict__ inv, const double* __restrict__ y,
                                               double* __restrict__ xhat, double* __restrict__ uvec,
-                                              double* __restrict__ ysol, double* lds, int* __restrict__ info) {
+                                              double* __restrict__ ysol, double* lds, int* __restrict__ info,
+                                              const RhsIn& R) {
   const int tid = threadIdx.x;
   const int w = T.w, r = T.r, Q = T.Qf, E = T.Ef;
   const int TS = r * Q;
@@ -2748,7 +2788,19 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
 #pragma unroll
   for (int e = 0; e < SOLVE_PREFETCH; ++e) pv[e] = (active && e < E) ? sp[(long long)e * TS] : 0.0;
   // front row tid: own right-hand side and, per child, which of its update rows lands here
-  double f0 = (tid < w) ? y[T.c0 + tid] : 0.0;
+  double f0 = 0.0;
+  if (R.Ar_ptr) {
+    // the front's own rows of t, formed here instead of by a launch in front of this one (every item does this
+    // at once when the launch starts; staged through the buffer of the partial sums, free until the product)
+    for (int row = tid / RL; row < w; row += ST / RL) {
+      const double s = rhs_row(R, T.c0 + row, tid % RL);
+      if (tid % RL == 0) part[row] = s;
+    }
+    __syncthreads();
+    if (tid < w) f0 = part[tid];
+  } else if (tid < w) {
+    f0 = y[T.c0 + tid];
+  }
   int iv[MAXCH];
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < r) ? inv[T.c_invoff[ch] + tid] : -1;
@@ -2845,14 +2897,14 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
                                                    double* __restrict__ xhat,
                                                    double* __restrict__ uvec, double* __restrict__ ysol2, int m,
                                                    const int* __restrict__ epoch, int* __restrict__ info,
-                                                   const int* __restrict__ skip) {
+                                                   const int* __restrict__ skip, RhsIn R) {
   __shared__ __attribute__((aligned(16))) double lds[2 * 1024 + 8];
   if (skip && *skip) return;
   const int par = *epoch & 1;  // constant during the launch: advanced by the kernel behind it
   const int b = blockIdx.x;
   if (b < nf) {
     const SolveItem& T = items[b];
-    dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info);
+    dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info, R);
   } else {
     const SolveItem& T = items[2 * nf - 1 - b];
     dev_solve_bwd(T, SPb, rows, y, xhat, uvec, ysol2 + (size_t)par * m, lds, info);
@@ -3016,13 +3068,6 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
 // Schur complement is formed without column j (Kprod), and afterwards x_j = beta,
 // y_bound = b_j - beta - (A^T y)_j.  Both maps null: the structure IS the caller's K.
 // ---------------------------------------------------------------------------
-struct SaddleMaps {
-  const int* __restrict__ vmap;
-  const int* __restrict__ cmap;
-  const double* __restrict__ dscale;  // per pivot position
-  int n;
-};
-__device__ __forceinline__ int ext_row(const SaddleMaps& M, int s) { return M.cmap ? M.cmap[s] : M.n + s; }
 
 // Device-side control block of the iterative refinement (no host round trip per solve): written
 // by the last block of every residual kernel, read by the kernels of the correction passes,
@@ -3042,7 +3087,6 @@ struct RefineCtl {
 
 // 16 lanes per row (rows of A hold ~20 entries in the headline configuration):
 // consecutive lanes read consecutive entries, fixed shuffle tree => deterministic.
-constexpr int RL = 16;
 
 // Row equilibration, values of A^ in pivot order (Ar_val), and the scaled copy of K's values in K's
 // own order: Ksc for the x update, Kprod for the Schur-complement products (the same array unless
@@ -3145,25 +3189,12 @@ __global__ __launch_bounds__(FB) void k_rhs_saddle(int m, const int* __restrict_
                                                    const double* __restrict__ b, double* __restrict__ t,
                                                    const int* __restrict__ skip) {
   if (skip && *skip) return;
+  const RhsIn R{Ar_ptr, Ar_col, Ar_val, perm, M, b};
   const int sub = threadIdx.x % RL;
   const int rpb = FB / RL;
   for (int k = blockIdx.x * rpb + threadIdx.x / RL; k < m; k += gridDim.x * rpb) {
-    double s = 0.0;
-    const int p1 = Ar_ptr[k + 1];
-    if (M.vmap) {
-      for (int p = Ar_ptr[k] + sub; p < p1; p += RL) {
-        const int j = Ar_col[p], v = M.vmap[j];
-        s += Ar_val[p] * b[v >= 0 ? v : j];
-      }
-    } else {
-      for (int p = Ar_ptr[k] + sub; p < p1; p += RL) s += Ar_val[p] * b[Ar_col[p]];
-    }
-#pragma unroll
-    for (int o = RL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, RL);
-    if (sub == 0) {
-      const int i = ext_row(M, perm[k]);
-      t[k] = i >= 0 ? s - b[i] * M.dscale[k] : 0.0;
-    }
+    const double s = rhs_row(R, k, sub);
+    if (sub == 0) t[k] = s;
   }
 }
 

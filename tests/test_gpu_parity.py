@@ -678,6 +678,36 @@ def test_solve_panels_built_inside_the_top_of_tree_launch(fact):
     fact.set_option("refine_steps", 1)
 
 
+def test_right_hand_side_formed_inside_the_solve_launch(fact):
+    """The forward items of the single-launch solve form their own rows of t = A^ b_x - D b_y (16 lanes per
+    row, the partial sums and the shuffle tree of k_rhs_saddle) instead of reading what a launch in front of
+    them left: same bits, with and without working-set maps, first pass and correction passes."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 4)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    rng = np.random.default_rng(12)
+    rhs = [rng.standard_normal(N) for _ in range(3)]
+    outs = {}
+    for fused in (1, 0):
+        fact.set_option("rhs_fused", fused)
+        fact.set_option("refine_adaptive", 0)  # every in-graph pass runs: the correction pass is exercised too
+        fact.set_option("refine_steps", 1)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("fused_solve") == 1.0
+        res = []
+        for b in rhs:
+            fact.solve(b)
+            res.append(fact.solution_raw(0, N))
+        outs[fused] = res
+    for a, b_ in zip(outs[1], outs[0]):
+        assert np.array_equal(a, b_)
+    assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-9
+    fact.set_option("rhs_fused", 1)
+    fact.set_option("refine_adaptive", 1)
+
+
 def test_solve_sequence_with_changing_right_hand_sides(fact):
     """The single-launch solve sweeps exchange vectors element by element through slots that the
     opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
