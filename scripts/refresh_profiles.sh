@@ -16,5 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3
 cd $REPO
 python scripts/pmc_summary.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.txt 2>&1
 find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+# the bench line below reads roofline.traffic from profiles/ (and checks the kernel sources' hash recorded in it)
+cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/${TAG}_pmc_traffic.json
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --workload uniform_n1e4_m5e3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_config3.json 2>> $OUT/${TAG}_bench.err
