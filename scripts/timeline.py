@@ -138,6 +138,16 @@ def run():
         w_ = tt[pv, 1]; w_ = w_[w_ > 0]
         print(f"  level {l:2d}  fronts {int(pv.sum()):4d}  panel wgs {int(pn.sum()):4d}  schur wgs {int(sc.sum()):5d}  pivots start {mn(tt[pv, 0]):7.1f}  waited {mn(w_) if w_.size else 0:7.1f} .. {mx(w_) if w_.size else 0:7.1f}"
               f"  pivots done {mx(tt[pv, 2]):7.1f}  panels published {mx(tt[pn, 3]):7.1f}  schur published {mx(tt[sc, 3]):7.1f}")
+    print("# per level and role: workgroups, mean us resident before their wait ended, mean us of work behind the wait, mean us to publish; "
+          "(panel / Schur: the wait is for the own front's pivot / panel workgroups)")
+    for l in range(int(f.info("factor_top_level")), P.nlevels):
+        m_ = (lev[front] == l) & (role < 3)
+        parts = []
+        for rr, nm in ((0, "pivot"), (1, "panel"), (2, "schur")):
+            k_ = m_ & (role == rr) & (tt[:, 1] > 0) & (tt[:, 2] > 0)
+            if k_.any():
+                parts.append(f"{nm} {int(k_.sum()):4d}: wait {np.mean(tt[k_, 1] - tt[k_, 0]):6.1f}  work {np.mean(tt[k_, 2] - tt[k_, 1]):5.1f}  publish {np.mean(tt[k_, 3] - tt[k_, 2]):4.1f}")
+        print(f"  level {l:2d}  " + "   ".join(parts))
     names = ["pivot", "panel", "schur", "spanl"]
     sp = role == 3
     if sp.any():
