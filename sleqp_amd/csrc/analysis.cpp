@@ -334,14 +334,18 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   // ---- structure detection: K = [I A^T; A 0] with empty trailing columns
   int n = N;
   while (n > 0 && Kp[n] == Kp[n - 1]) --n;
-  bool saddle = !prm.force_generic;
-  if (n == 0 && N > 0) saddle = false;  // all-zero matrix
-  for (int j = 0; j < n && saddle; ++j) {
+  bool shape = !prm.force_generic;
+  if (n == 0 && N > 0) shape = false;  // all-zero matrix
+  for (int j = 0; j < n && shape; ++j) {
     const int e0 = Kp[j];
-    if (Kp[j + 1] == e0 || Ki[e0] != j) saddle = false;
-    else if (Kx && Kx[e0] != 1.0) saddle = false;
-    else if (Kp[j + 1] > e0 + 1 && Ki[e0 + 1] < n) saddle = false;
+    if (Kp[j + 1] == e0 || Ki[e0] != j) shape = false;
+    else if (Kp[j + 1] > e0 + 1 && Ki[e0 + 1] < n) shape = false;
   }
+  bool saddle = shape;
+  for (int j = 0; j < n && saddle; ++j)
+    if (Kx && Kx[Kp[j]] != 1.0) saddle = false;
+  P.saddle_shape = shape;
+  P.n_shape = shape ? n : 0;
   P.saddle = saddle;
   P.n = saddle ? n : 0;
   P.m = saddle ? N - n : N;

@@ -249,6 +249,8 @@ struct hipfact_handle : PlanState {
   bool equilibrate = true;       // row equilibration of the constraint block (saddle mode)
   long num_refined = 0;          // solves that applied at least one correction pass
   long num_passes = 0;           // correction passes applied in total
+  bool decide_lazy = true;       // verdict of a solve without correction passes delivered by the next tree launch
+  bool decide_deferred = false;  // ... and such a verdict is outstanding
   bool ctl_pending = false;      // the control block of the last solve has not been looked at yet
   const double* last_b = nullptr;
   double* last_z = nullptr;
@@ -1183,7 +1185,11 @@ static int factor_enqueue(hipfact_handle* h) {
 template <class F>
 static int run_cached(hipfact_handle* h, int kind, const void* b, void* z, F enqueue, int passes = 0);
 
+static void flush_decide(hipfact_handle* h);
+static DecideIn decide_in(hipfact_handle* h);
+
 static int factor_async(hipfact_handle* h) {
+  flush_decide(h);  // a deferred verdict is judged against the pivot range of the factorisation it belongs to
   const int rc = run_cached(h, 0, nullptr, nullptr, [&] { return factor_enqueue(h); });
   if (rc) return rc;
   h->num_factor++;
@@ -1276,11 +1282,13 @@ static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
 static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs = nullptr) {
   const Plan& P = h->plan;
   if (h->fused_solve && !h->no_dataflow) {
-    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
+    // (one workgroup more than items: it delivers the deferred verdict of the previous solve, if any)
+    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper + 1), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
            h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
            h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_xhat.as<double>(), h->d_uvec.as<double>(), h->d_ysol.as<double>(), P.m, h->d_epoch.as<int>(),
-           h->d_info.as<int>(), skip, rhs ? *rhs : RhsIn{nullptr, nullptr, nullptr, nullptr, SaddleMaps{nullptr, nullptr, nullptr, 0}, nullptr});
+           h->d_info.as<int>(), skip, rhs ? *rhs : RhsIn{nullptr, nullptr, nullptr, nullptr, SaddleMaps{nullptr, nullptr, nullptr, 0}, nullptr},
+           decide_in(h));
     return;
   }
   const int ltop = h->no_dataflow ? P.nlevels : std::min(h->top_level, P.nlevels);
@@ -1354,24 +1362,39 @@ static inline int resid_blocks(const Plan& P) {  // saddle: an even number >= 2 
   return P.saddle ? std::max(2, nblocks((long long)P.N * 8, 2048) & ~1) : nblocks(P.N, 2048);
 }
 
-// res = b - K z; updates the refinement control block (first: the residual of the first pass)
-static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool first) {
+static DecideIn decide_in(hipfact_handle* h) {
+  // non-adaptive mode (negative target): every in-graph pass runs
+  return DecideIn{h->d_ctl.as<RefineCtl>(), static_cast<RefineCtl*>(h->h_ctl_dev), h->d_norms.as<double>(),
+                  resid_blocks(h->plan), h->refine_adaptive ? h->refine_tol : -1.0, minmax_ptr(h)};
+}
+
+// res = b - K z; updates the refinement control block (first: the residual of the first pass).  defer: no verdict
+// launch behind it - the next tree launch (or flush_decide) delivers it.
+static void residual_async(hipfact_handle* h, const double* b, const double* z, double* res, bool first,
+                           bool defer = false) {
   const Plan& P = h->plan;
   RefineCtl* ctl = h->d_ctl.as<RefineCtl>();
-  // non-adaptive mode (negative target): every in-graph pass runs
-  const double target = h->refine_adaptive ? h->refine_tol : -1.0;
+  int* dflag = defer ? &ctl->pending : nullptr;
   if (P.saddle) {
     LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
            h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
            h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl, h->d_norms.as<double>(),
-           first ? 1 : 0);
+           first ? 1 : 0, dflag);
   } else {
     LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(), h->d_Ki.as<int>(),
            h->d_Kval.as<double>(), h->d_Tp.as<int>(), h->d_Ti.as<int>(), h->d_Tsrc.as<int>(), b, z, res, ctl,
-           h->d_norms.as<double>(), first ? 1 : 0);
+           h->d_norms.as<double>(), first ? 1 : 0, dflag);
   }
-  LAUNCH(PC_RESID, k_refine_decide, dim3(1), dim3(FB), 0, ctl, static_cast<RefineCtl*>(h->h_ctl_dev),
-         h->d_norms.as<double>(), resid_blocks(P), first ? 1 : 0, target, minmax_ptr(h));
+  if (!defer) LAUNCH(PC_RESID, k_refine_decide, dim3(1), dim3(FB), 0, decide_in(h), first ? 1 : 0, 0);
+}
+
+// the verdict of a solve whose graph left it to the next tree launch, for whoever needs it before that
+// (a synchronising entry point, a refactorisation - the pivot range it is judged against changes -, a solve
+// that does not go through the tree launch); a no-op on the device if it has been delivered already
+static void flush_decide(hipfact_handle* h) {
+  if (!h->decide_deferred) return;
+  hipLaunchKernelGGL(k_refine_decide, dim3(1), dim3(FB), 0, h->stream, decide_in(h), 1, 1);
+  h->decide_deferred = false;
 }
 
 static void drop_graphs(hipfact_handle* h) { h->graphs.clear(); }
@@ -1435,6 +1458,13 @@ static int correct_enqueue(hipfact_handle* h, const double* bb, double* z, int p
   return HIPFACT_OK;
 }
 
+// A solve without correction passes in its graph leaves its verdict to the tree launch of the NEXT solve (a
+// workgroup of that launch instead of a one-block launch and its kernel boundary behind every solve).
+static bool defers_decide(const hipfact_handle* h) {
+  return h->decide_lazy && h->refine_steps > 0 && h->refine_adaptive && h->refine_inline == 0 && h->fused_solve &&
+         !h->no_dataflow && h->plan.m > 0 && h->plan.saddle;
+}
+
 // first pass z = K^-1 b, residual, and the in-graph correction passes
 static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
   const Plan& P = h->plan;
@@ -1445,7 +1475,7 @@ static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
   }
   solve_once_async(h, bb, z, false, nullptr);
   if (h->refine_steps > 0) {
-    residual_async(h, bb, z, h->d_res.as<double>(), true);
+    residual_async(h, bb, z, h->d_res.as<double>(), true, defers_decide(h));
     return correct_enqueue(h, bb, z, h->refine_inline);
   }
   HCHECK(h, hipGetLastError());
@@ -1467,8 +1497,12 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
       h->inline_probe = false;
     }
   }
-  int rc = run_cached(h, 1, b, z, [&] { return solve_enqueue(h, b, z); }, h->refine_steps > 0 ? h->refine_inline : -1);
+  const bool defer = defers_decide(h);
+  if (!(h->fused_solve && !h->no_dataflow && h->plan.m > 0 && h->plan.saddle)) flush_decide(h);  // no tree launch to deliver it
+  int rc = run_cached(h, 1, b, z, [&] { return solve_enqueue(h, b, z); },
+                      h->refine_steps > 0 ? (defer ? -2 : h->refine_inline) : -1);
   if (rc) return rc;
+  h->decide_deferred = defer;  // (the tree launch of this solve has delivered an older one)
   h->num_solve++;
   h->solved = true;
   if (h->refine_steps > 0) h->solve_seq++;
@@ -1484,6 +1518,7 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
 static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
   if (continued) *continued = false;
   if (!h->ctl_pending) return HIPFACT_OK;
+  flush_decide(h);
   HCHECK(h, hipStreamSynchronize(h->stream));
   RefineCtl c;
   memcpy(&c, h->h_ctl.p, sizeof(c));
@@ -1567,6 +1602,14 @@ static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* r
     if (s.plan.saddle && vals)
       for (int j = 0; j < s.plan.n; ++j)
         if (vals[colptr[j]] != 1.0) return false;
+    // ... both ways: a plan analysed as a general symmetric matrix (its values had no unit diagonal then) is not
+    // the plan for values that do make the structure a saddle matrix (K is indefinite: the constrained pivot order
+    // of the saddle mode is what makes static pivots safe)
+    if (!s.plan.saddle && s.plan.saddle_shape && vals) {
+      bool unit = true;
+      for (int j = 0; j < s.plan.n_shape && unit; ++j) unit = vals[colptr[j]] == 1.0;
+      if (unit) return false;
+    }
     return true;
   };
   bool hit = matches(*h);
@@ -1682,6 +1725,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_DECIDE_LAZY")) h->decide_lazy = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SPANEL_ROOM")) h->spanel_fold_room = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
   if (const char* s = getenv("HIPFACT_TOP_MAX")) h->top_max_fronts = atoi(s);
@@ -2742,6 +2786,14 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   }
   if (!strcmp(name, "debug_fake_timeout")) {  // test hook for the fallback to the per-level launches
     h->fake_timeouts = (int)value;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "decide_lazy")) {  // 0: every solve graph ends with its own verdict launch
+    if (h->decide_lazy != (value != 0.0)) {
+      flush_decide(h);
+      drop_graphs(h);
+    }
+    h->decide_lazy = value != 0.0;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "rhs_fused")) {  // 0: k_rhs_saddle in front of the single-launch solve

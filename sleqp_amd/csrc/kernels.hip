@@ -2727,6 +2727,117 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
 // so it must never find the previous solve's value - the copy of the previous launch is put back to
 // the sentinel by the forward items while this launch exchanges through the other one.
 // ---------------------------------------------------------------------------
+// ---- refinement control block (described with the residual kernels below)
+struct RefineCtl {
+  int done;     // 1: stop (converged, stagnated or non-finite)
+  int iters;    // correction passes applied so far
+  int status;   // 0 converged, 1 stagnated above the tolerance, 2 non-finite residual, 3 still running
+  int pending;  // 1: the residual of a solve has left its partial maxima and nobody has judged them yet (deferred verdict)
+  int seq;      // number of solves whose first residual has been judged (lets the host match a copy to a solve)
+  int pad;
+  double omega;       // ||r^||_inf / (||z^||_inf + ||b^||_inf), equilibrated space
+  double omega_prev;
+  double tol;         // effective tolerance of this solve
+  double kappa;       // pivot-ratio condition estimate used for it
+};
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+// Reduces the partial maxima a residual kernel has left and updates the control block: one workgroup (any size
+// that is a multiple of 64, at most 1024 threads).  (An election of the last block inside the residual kernel
+// costs more: thousands of blocks each end with a dependent store -> ticket round trip, and increments of one
+// word serialise.)
+struct DecideIn {
+  RefineCtl* ctl;
+  RefineCtl* hctl;  // pinned copy for the host
+  const double* partials;
+  int nblk;
+  double target;
+  const unsigned long long* minmax;
+};
+__device__ __forceinline__ void dev_refine_decide(const DecideIn& D, int first) {
+  RefineCtl* __restrict__ ctl = D.ctl;
+  RefineCtl* __restrict__ hctl = D.hctl;
+  __shared__ double sh[3][16];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  double r = 0.0, bb = 0.0, zz = 0.0;
+  for (int q = tid; q < D.nblk; q += nthr) {
+    r = nanmax(r, D.partials[3 * q]);
+    bb = nanmax(bb, D.partials[3 * q + 1]);
+    zz = nanmax(zz, D.partials[3 * q + 2]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r = nanmax(r, __shfl_down(r, o, 64));
+    bb = nanmax(bb, __shfl_down(bb, o, 64));
+    zz = nanmax(zz, __shfl_down(zz, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    sh[0][tid >> 6] = r;
+    sh[1][tid >> 6] = bb;
+    sh[2][tid >> 6] = zz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = 1; q < nthr / 64; ++q) {
+      r = nanmax(r, sh[0][q]);
+      bb = nanmax(bb, sh[1][q]);
+      zz = nanmax(zz, sh[2][q]);
+    }
+    const unsigned long long* minmax = D.minmax;
+    const double target = D.target;
+    const double lo = __longlong_as_double((long long)~minmax[0]), hi = __longlong_as_double((long long)minmax[1]);
+    const double kappa = (minmax[1] == 0ull) ? 10.0 : ((lo > 0.0 && hi >= lo) ? 10.0 * hi / lo : 1e300);
+    const double tol = fmin(1e-12, fmax(4.5e-16, target / kappa));
+    const double den = zz + bb;
+    const double omega = (r == 0.0) ? 0.0 : r / den;  // den == 0 with r != 0 cannot happen; NaN stays NaN
+    const int iters = first ? 0 : ctl->iters + 1;
+    const int seq = ctl->seq + (first ? 1 : 0);
+    const double prev = first ? 1.7e308 : ctl->omega;
+    int done = 0, status = 3;
+    if (!(omega == omega) || !(den < 1.7e308)) {
+      done = 1;
+      status = 2;
+    } else if (target < 0.0) {
+      // non-adaptive mode: the passes of the graph run unconditionally
+    } else if (omega <= tol) {
+      done = 1;
+      status = 0;
+    } else if (!first && omega > 0.5 * prev) {
+      done = 1;
+      status = 1;
+    }
+    ctl->iters = iters;
+    ctl->omega_prev = prev;
+    ctl->omega = omega;
+    ctl->tol = tol;
+    ctl->kappa = kappa;
+    ctl->status = status;
+    ctl->seq = seq;
+    ctl->pending = 0;
+    ctl->done = done;  // read by the kernels of the next pass: a kernel boundary away
+    // copy for the host in pinned memory (visible after the stream has been synchronised): no copy node
+    hctl->iters = iters;
+    hctl->omega_prev = prev;
+    hctl->omega = omega;
+    hctl->tol = tol;
+    hctl->kappa = kappa;
+    hctl->status = status;
+    hctl->done = done;
+    // last, relaxed: the stores of one thread to host memory arrive in order (the host may peek without a sync)
+    __hip_atomic_store(&hctl->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// The verdict as a launch of its own.  pending_only: the deferred verdict of a solve whose graph carries none
+// (the first pass of a solve without correction passes; normally picked up by the next solve's tree launch) -
+// nothing happens if it has been delivered already.
+__global__ __launch_bounds__(FB) void k_refine_decide(DecideIn D, int first, int pending_only) {
+  if (pending_only) {
+    if (!D.ctl->pending) return;
+  } else if (!first && D.ctl->done) {
+    return;
+  }
+  dev_refine_decide(D, first);
+}
+
 // (working-set maps and equilibration of the saddle-point front end: described with the saddle kernels below)
 struct SaddleMaps {
   const int* __restrict__ vmap;
@@ -2897,11 +3008,18 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
                                                    double* __restrict__ xhat,
                                                    double* __restrict__ uvec, double* __restrict__ ysol2, int m,
                                                    const int* __restrict__ epoch, int* __restrict__ info,
-                                                   const int* __restrict__ skip, RhsIn R) {
+                                                   const int* __restrict__ skip, RhsIn R, DecideIn D) {
   __shared__ __attribute__((aligned(16))) double lds[2 * 1024 + 8];
+  const int b = blockIdx.x;
+  if (b == 2 * nf) {
+    // one workgroup more than the tree has items: the verdict on the PREVIOUS solve, if its graph carried none
+    // (steady state of a well-conditioned factorisation: no correction pass, and this saves the one-block launch
+    // and its kernel boundary behind every solve; an entry point that needs the verdict earlier launches it)
+    if (D.ctl && D.ctl->pending) dev_refine_decide(D, 1);
+    return;
+  }
   if (skip && *skip) return;
   const int par = *epoch & 1;  // constant during the launch: advanced by the kernel behind it
-  const int b = blockIdx.x;
   if (b < nf) {
     const SolveItem& T = items[b];
     dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info, R);
@@ -3072,18 +3190,6 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
 // Device-side control block of the iterative refinement (no host round trip per solve): written
 // by the last block of every residual kernel, read by the kernels of the correction passes,
 // which return at once when `done` is set.
-struct RefineCtl {
-  int done;     // 1: stop (converged, stagnated or non-finite)
-  int iters;    // correction passes applied so far
-  int status;   // 0 converged, 1 stagnated above the tolerance, 2 non-finite residual, 3 still running
-  int counter;  // blocks that have delivered their partial maxima (last-block election)
-  int seq;      // number of solves whose first residual has been judged (lets the host match a copy to a solve)
-  int pad;
-  double omega;       // ||r^||_inf / (||z^||_inf + ||b^||_inf), equilibrated space
-  double omega_prev;
-  double tol;         // effective tolerance of this solve
-  double kappa;       // pivot-ratio condition estimate used for it
-};
 
 // 16 lanes per row (rows of A hold ~20 entries in the headline configuration):
 // consecutive lanes read consecutive entries, fixed shuffle tree => deterministic.
@@ -3253,7 +3359,6 @@ __global__ __launch_bounds__(FB) void k_x_saddle(int n, int m, const int* __rest
 //   tol = clamp(target / kappa, 4.5e-16, 1e-12), kappa = 10 max|d| / min|d| of the pivots: the
 //   forward error of a solve with backward error omega is about kappa omega, so well conditioned
 //   systems are accepted after the first pass and ill conditioned ones are refined to the limit.
-__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 
 // block partials of a residual kernel: plain stores, the decision is taken by the kernel behind it
 __device__ __forceinline__ void refine_partials(double* __restrict__ partials, double mr, double mb, double mz) {
@@ -3283,81 +3388,6 @@ __device__ __forceinline__ void refine_partials(double* __restrict__ partials, d
   }
 }
 
-// One block: reduces the partial maxima of the residual kernel in front of it and updates the control block.
-// (An election of the last block inside the residual kernel costs more: thousands of blocks each end with a
-// dependent store -> ticket round trip, and increments of one word serialise.)
-__global__ __launch_bounds__(FB) void k_refine_decide(RefineCtl* __restrict__ ctl, RefineCtl* __restrict__ hctl,
-                                                      const double* __restrict__ partials, int nblk, int first,
-                                                      double target, const unsigned long long* __restrict__ minmax) {
-  if (!first && ctl->done) return;
-  __shared__ double sh[3][FB / 64];
-  const int tid = threadIdx.x;
-  double r = 0.0, bb = 0.0, zz = 0.0;
-  for (int q = tid; q < nblk; q += FB) {
-    r = nanmax(r, partials[3 * q]);
-    bb = nanmax(bb, partials[3 * q + 1]);
-    zz = nanmax(zz, partials[3 * q + 2]);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    r = nanmax(r, __shfl_down(r, o, 64));
-    bb = nanmax(bb, __shfl_down(bb, o, 64));
-    zz = nanmax(zz, __shfl_down(zz, o, 64));
-  }
-  if ((tid & 63) == 0) {
-    sh[0][tid >> 6] = r;
-    sh[1][tid >> 6] = bb;
-    sh[2][tid >> 6] = zz;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int q = 1; q < FB / 64; ++q) {
-      r = nanmax(r, sh[0][q]);
-      bb = nanmax(bb, sh[1][q]);
-      zz = nanmax(zz, sh[2][q]);
-    }
-    const double lo = __longlong_as_double((long long)~minmax[0]), hi = __longlong_as_double((long long)minmax[1]);
-    const double kappa = (minmax[1] == 0ull) ? 10.0 : ((lo > 0.0 && hi >= lo) ? 10.0 * hi / lo : 1e300);
-    const double tol = fmin(1e-12, fmax(4.5e-16, target / kappa));
-    const double den = zz + bb;
-    const double omega = (r == 0.0) ? 0.0 : r / den;  // den == 0 with r != 0 cannot happen; NaN stays NaN
-    const int iters = first ? 0 : ctl->iters + 1;
-    const int seq = ctl->seq + (first ? 1 : 0);
-    const double prev = first ? 1.7e308 : ctl->omega;
-    int done = 0, status = 3;
-    if (!(omega == omega) || !(den < 1.7e308)) {
-      done = 1;
-      status = 2;
-    } else if (target < 0.0) {
-      // non-adaptive mode: the passes of the graph run unconditionally
-    } else if (omega <= tol) {
-      done = 1;
-      status = 0;
-    } else if (!first && omega > 0.5 * prev) {
-      done = 1;
-      status = 1;
-    }
-    ctl->iters = iters;
-    ctl->omega_prev = prev;
-    ctl->omega = omega;
-    ctl->tol = tol;
-    ctl->kappa = kappa;
-    ctl->status = status;
-    ctl->seq = seq;
-    ctl->done = done;  // read by the kernels of the next pass: a kernel boundary away
-    // copy for the host in pinned memory (visible after the stream has been synchronised): no copy node
-    hctl->iters = iters;
-    hctl->omega_prev = prev;
-    hctl->omega = omega;
-    hctl->tol = tol;
-    hctl->kappa = kappa;
-    hctl->status = status;
-    hctl->done = done;
-    // last, relaxed: the stores of one thread to host memory arrive in order (the host may peek without a sync)
-    __hip_atomic_store(&hctl->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // res = b - K z for the saddle matrix (columns < n of the lower CSC hold I and A), in the caller's
 // numbering.  Two sweeps with cooperative lanes (8 per column of K, 16 per row of A); the last
 // block updates the refinement control block (ctl null: plain residual).
@@ -3368,7 +3398,7 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
                                                         const int* __restrict__ perm, SaddleMaps M,
                                                         const double* __restrict__ b, const double* __restrict__ z,
                                                         double* __restrict__ res, const RefineCtl* __restrict__ ctl,
-                                                        double* __restrict__ partials, int first) {
+                                                        double* __restrict__ partials, int first, int* __restrict__ defer) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
   // The two sweeps are chains of three dependent gathers each (pointer -> index / value -> vector entry);
@@ -3439,6 +3469,7 @@ __global__ __launch_bounds__(FB) void k_residual_saddle(int n, int m, const int*
     }
   }
   if (ctl) refine_partials(partials, mr, mb, mz);
+  if (defer && blockIdx.x == 0 && threadIdx.x == 0) *defer = 1;  // picked up a kernel boundary (or more) later
 }
 
 // Generic mode residual: res = b - (L + L^T - diag) z with L lower CSC and its
@@ -3448,7 +3479,7 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
                                                      const int* __restrict__ Ti, const int* __restrict__ Tsrc,
                                                      const double* __restrict__ b, const double* __restrict__ z,
                                                      double* __restrict__ res, const RefineCtl* __restrict__ ctl,
-                                                     double* __restrict__ partials, int first) {
+                                                     double* __restrict__ partials, int first, int* __restrict__ defer) {
   if (ctl && !first && ctl->done) return;
   double mr = 0.0, mb = 0.0, mz = 0.0;
   const int iters = (N + gridDim.x * FB - 1) / (gridDim.x * FB);
@@ -3467,6 +3498,7 @@ __global__ __launch_bounds__(FB) void k_residual_sym(int N, const int* __restric
     }
   }
   if (ctl) refine_partials(partials, mr, mb, mz);
+  if (defer && blockIdx.x == 0 && threadIdx.x == 0) *defer = 1;  // picked up a kernel boundary (or more) later
 }
 
 // y += a x, or nothing when *skip is set

@@ -43,6 +43,8 @@ struct Plan {
   int n = 0;  // saddle: number of x columns; generic: 0
   int m = 0;  // order of M (saddle: constraints, generic: N)
   bool saddle = false;
+  bool saddle_shape = false;  // the STRUCTURE is [I A^T; A 0] (saddle = structure and unit diagonal values)
+  int n_shape = 0;            // ... with this many x columns
   int64_t nnzK = 0;
   std::vector<int> Kp, Ki;  // pattern of K the plan was built for (cache key)
 

@@ -708,6 +708,72 @@ def test_right_hand_side_formed_inside_the_solve_launch(fact):
     fact.set_option("refine_adaptive", 1)
 
 
+def test_general_symmetric_plan_is_not_reused_for_saddle_values(fact):
+    """The saddle classification needs the structure [I A^T; A 0] AND a unit diagonal.  The same pattern with
+    other diagonal values is analysed as a general symmetric matrix - and that plan must not be picked up again
+    when values with a unit diagonal come back (K is indefinite; only the constrained pivot order of the saddle
+    mode makes static pivots safe), nor the saddle plan for the general values."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(400, 150, "b", 0.0, 2)
+    N, kc, kr, kd = oracle.fill_aug_jac(400, 150, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    b = np.random.default_rng(3).standard_normal(N)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("saddle") == 1.0
+    fact.solve(b)
+    z0 = fact.solution_raw(0, N)
+    # diagonally dominant SPD-like values on the same pattern: trailing columns are empty, so only the x block
+    spd = kd.copy()
+    spd[kc[:-1][:400]] = 50.0
+    fact.set_matrix(SleqpMat(N, N, kc, kr, spd))
+    assert fact.info("saddle") == 0.0
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("saddle") == 1.0
+    fact.solve(b)
+    assert np.array_equal(fact.solution_raw(0, N), z0)
+    assert scaled_residual(K, z0, b) <= 1e-9
+
+
+def test_deferred_refinement_verdict(fact):
+    """A solve whose graph carries no correction pass (steady state of a well-conditioned factorisation) leaves
+    its verdict to a workgroup of the NEXT solve's tree launch; entry points that need it earlier launch it
+    themselves, and a refactorisation flushes it first (it is judged against that factorisation's pivots).
+    Same solutions, same backward errors and pass counts as with a verdict launch behind every solve, over
+    solves, refactorisations with different values and checks in between."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 6)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    rng = np.random.default_rng(21)
+    rhs = [rng.standard_normal(N) for _ in range(6)]
+    scale = [1.0, 3.0, 0.25]
+    diag = kc[:-1][:20000]  # position of the unit diagonal entry of every x column (scaled values keep the saddle form)
+    logs = {}
+    for lazy in (1, 0):
+        fact.set_option("decide_lazy", lazy)
+        log = []
+        for rep, sc in enumerate(scale):
+            vals = kd * sc
+            vals[diag] = 1.0
+            fact.set_matrix(SleqpMat(N, N, kc, kr, vals))
+            assert fact.info("saddle") == 1.0
+            for i, b in enumerate(rhs):
+                fact.solve(b)
+                if (i + rep) % 3 == 2:  # the host asks for the verdict now and then, not after every solve
+                    fact.check()
+                    log.append((fact.solution_raw(0, N), fact.info("last_omega"), fact.info("last_iters"), fact.info("last_status")))
+            fact.check()
+            log.append((fact.solution_raw(0, N), fact.info("last_omega"), fact.info("last_iters"), fact.info("last_status")))
+        logs[lazy] = log
+    assert len(logs[0]) == len(logs[1])
+    for (za, oa, ia, sa), (zb, ob, ib, sb) in zip(logs[1], logs[0]):
+        assert np.array_equal(za, zb)
+        assert oa == ob and ia == ib and sa == sb
+        assert sa == 0.0 and oa <= 1e-12
+    fact.set_option("decide_lazy", 1)
+
+
 def test_solve_sequence_with_changing_right_hand_sides(fact):
     """The single-launch solve sweeps exchange vectors element by element through slots that the
     opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
