@@ -2023,17 +2023,24 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
     h->error = "hipfact_assemble_kkt: working_set_size does not match the index maps";
     return HIPFACT_EINVAL;
   }
-  for (int q = 0; q < jnnz; ++q)
-    if (j_rowidx[q] < 0 || j_rowidx[q] >= m_total) {
-      h->error = "hipfact_assemble_kkt: Jacobian row index out of range";
-      return HIPFACT_EINVAL;
-    }
+  // Steady state of an SQP run: the pattern of J is the one the active plan was built from.  One comparison against
+  // the plan's copy then replaces the range check, the hash and the comparison in the plan search below.
+  const bool known = h->have_plan && h->from_jacobian && h->plan.n == n && (int)h->sidx.size() == m_total &&
+                     (int)h->Ji.size() == jnnz && memcmp(h->Jp.data(), j_colptr, (size_t)(n + 1) * sizeof(int)) == 0 &&
+                     (jnnz == 0 || memcmp(h->Ji.data(), j_rowidx, (size_t)jnnz * sizeof(int)) == 0);
+  if (!known)
+    for (int q = 0; q < jnnz; ++q)
+      if (j_rowidx[q] < 0 || j_rowidx[q] >= m_total) {
+        h->error = "hipfact_assemble_kkt: Jacobian row index out of range";
+        return HIPFACT_EINVAL;
+      }
   const size_t cap = (size_t)n + jnnz + nav;  // reserve_aug_jac (standard_aug_jac.c:106-133)
   hipStream_t st = h->stream;
   HCHECK(h, hipStreamSynchronize(st));  // the buffers below may still be read by queued work
   const bool want_arrays = k_colptr || k_rowidx || k_vals;
   // ---- the Jacobian and the working-set maps go to the device (the pattern only when it changed)
-  const unsigned long long jhash = hash_ints(j_rowidx, (size_t)jnnz, hash_ints(j_colptr, (size_t)n + 1));
+  const unsigned long long jhash =
+      known ? h->key_hash : hash_ints(j_rowidx, (size_t)jnnz, hash_ints(j_colptr, (size_t)n + 1));
   const bool same_pattern = h->jdev_valid && h->jdev_hash == jhash && h->jdev_n == n && h->jdev_nnz == jnnz;
   HCHECK(h, h->d_jp.ensure((size_t)(n + 1) * sizeof(int)));
   HCHECK(h, h->d_ji.ensure(std::max<size_t>((size_t)jnnz * sizeof(int), 16)));
@@ -2083,7 +2090,7 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
     if (k_colptr) memcpy(k_colptr, kp.data(), (size_t)(N + 1) * sizeof(int));
     if (k_rowidx && nnz > 0) memcpy(k_rowidx, ki.data(), (size_t)nnz * sizeof(int));
     if (k_vals && nnz > 0) HCHECK(h, hipMemcpy(k_vals, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-  } else {
+  } else if (k_nnz) {
     nnz = n + nav;
     for (int q = 0; q < jnnz; ++q) nnz += (cons_index[j_rowidx[q]] >= 0);
   }
@@ -2099,7 +2106,8 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
   }
   // ---- superset path: find a plan whose structure covers the working set's constraint rows
   auto covers = [&](const PlanState& s) {
-    if (!(s.have_plan && s.from_jacobian && s.plan.n == n && (int)s.sidx.size() == m_total && s.key_hash == jhash &&
+    if (!(&s == static_cast<const PlanState*>(h) && known) &&
+        !(s.have_plan && s.from_jacobian && s.plan.n == n && (int)s.sidx.size() == m_total && s.key_hash == jhash &&
           (int)s.Ji.size() == jnnz && memcmp(s.Jp.data(), j_colptr, (size_t)(n + 1) * sizeof(int)) == 0 &&
           (jnnz == 0 || memcmp(s.Ji.data(), j_rowidx, (size_t)jnnz * sizeof(int)) == 0)))
       return false;

@@ -126,7 +126,7 @@ class HipFact:
         kx = np.empty(max(cap, 1), dtype=np.float64) if want_arrays else None
         self._check(self._lib.hipfact_assemble_kkt(self._h, n, m_total, _ptr(J.cols), _ptr(J.rows), _ptr(J.data),
                                                    _ptr(var_index), _ptr(cons_index), working_set_size,
-                                                   C.byref(k_nnz), _ptr(kp), _ptr(ki), _ptr(kx)))
+                                                   C.byref(k_nnz) if want_arrays else None, _ptr(kp), _ptr(ki), _ptr(kx)))
         self.N = N
         if not want_arrays:
             return None
