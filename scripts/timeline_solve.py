@@ -5,7 +5,7 @@ directory; per workgroup the stamps are kernel entry, begin / end of its last de
 work done, published.
 
     python scripts/timeline_solve.py build     # here
-    python scripts/timeline_solve.py run       # on the GPU box (gpurun)
+    python scripts/timeline_solve.py run [workload]      # on the GPU box (gpurun); default banded_n1e5_m5e4
 """
 import ctypes as C
 import os
@@ -69,9 +69,10 @@ def run():
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
-    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    J, N, cp, ri, vx, b = make_problem(sys.argv[2] if len(sys.argv) > 2 else "banded_n1e5_m5e4", 0)
     f = HipFact(device=0)
     f.set_option("use_graph", 0)
+    f.set_option("solve_fused", 0)  # the two-launch sweeps are what this script instruments
     f.set_matrix(SleqpMat(N, N, cp, ri, vx))
     dev = torch.device("cuda", 0)
     d_rhs = torch.from_numpy(b).to(dev)

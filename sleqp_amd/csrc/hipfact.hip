@@ -268,7 +268,7 @@ struct hipfact_handle : PlanState {
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int factor_top_post = 64;   // levels with at most this many fronts post the pivot block to polling panel workgroups
-  int wide_min_rows = 1024;   // fronts with at least this many update rows are solved by several workgroups (0: off)
+  int wide_min_rows = 256;    // fronts with at least this many update rows are solved by several workgroups (0: off; one workgroup streams a panel at ~50 GB/s)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
   int panel_small_below = 0;  // levels with fewer 128-row panel blocks use 64-row blocks
   int pull_max_children = 4;  // 0: always the separate assembly kernel; otherwise pull for any number of children
@@ -891,7 +891,7 @@ static int upload_plan(hipfact_handle* h) {
             T.nsl = nsl;
             T.poff = wpart_size;
             wpart_size += (long long)nsl * T.w;
-            lf = lb = ((size_t)10 * T.w + WIDE_SLICE_ROWS + 1024 + 2) * sizeof(double);
+            lf = lb = ((size_t)10 * T.w + WIDE_SLICE_ROWS + 1024 + 2 + (size_t)nsl * T.w) * sizeof(double);
             titems.push_back(T);
             for (int q2 = 0; q2 < nsl; ++q2) {
               TopItem S2 = T;
@@ -910,6 +910,8 @@ static int upload_plan(hipfact_handle* h) {
       h->top_count = (int)titems.size();
       if ((rc = upload(h, h->d_ftarget, ftarget))) return rc;
       HCHECK(h, h->d_wpart.ensure(std::max<size_t>((size_t)wpart_size * sizeof(double), 16)));
+      // (polled by the heads of the sliced fronts: sentinel between solves)
+      HCHECK(h, hipMemsetAsync(h->d_wpart.p, 0xFF, std::max<size_t>((size_t)wpart_size * sizeof(double), 16), h->stream));
       if ((rc = upload(h, h->d_top_sn, top))) return rc;
       if ((rc = upload(h, h->d_titems, titems))) return rc;
     }
@@ -1212,6 +1214,7 @@ static int reset_dataflow_state(hipfact_handle* h) {
   if (h->d_uvec.p) HCHECK(h, hipMemsetAsync(h->d_uvec.p, 0xFF, std::max<size_t>((size_t)P.u_size * sizeof(double), 16), st));
   if (h->d_ysol.p) HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)2 * P.m * sizeof(double), 16), st));
   if (h->d_xhat.p) HCHECK(h, hipMemsetAsync(h->d_xhat.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), st));
+  if (h->d_wpart.p) HCHECK(h, hipMemsetAsync(h->d_wpart.p, 0xFF, h->d_wpart.bytes, st));
   if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
   HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));

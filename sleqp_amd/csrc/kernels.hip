@@ -2406,9 +2406,24 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
 //             head: waits for its slices; v = z / d - sum_s partial_s (fixed order), x = v + lower(inv(L11))^T v
 //                                                                     -> flags[F] = 1
 // Children's contributions are gathered through the inverse relative indices (no scatter, child order).
+// The head's share of inv(L11): thread (row k = tid & 127, segment p = tid >> 7 of eight) owns the entries
+// t in [k p / 8, k (p + 1) / 8) of row k - at most 16 for w <= 128.  They do not depend on the children: requested
+// BEFORE the children are awaited (sixteen strided global loads per thread behind the wait were 4 of the 5 us a
+// head spent on the critical path of every level of a dense chain, scripts/timeline_solve.py).
+__device__ __forceinline__ void dev_fwd_wide_head_prefetch(const TopItem& T, const double* __restrict__ L,
+                                                           double (&xr)[16]) {
+  const int tid = threadIdx.x;
+  const int w = T.w, r = T.r;
+  const double* __restrict__ P = L + T.Loff;
+  const int k = tid & 127, p = tid >> 7;
+  const int lo = (int)(((long long)k * p) >> 3), hi = (int)(((long long)k * (p + 1)) >> 3);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xr[j] = (k < w && lo + j < hi) ? P[k + (long long)(lo + j) * r] : 0.0;
+}
 __device__ __forceinline__ void dev_fwd_wide_head(const TopItem& T, const double* __restrict__ L,
                                                   const int* __restrict__ rel, double* __restrict__ y,
-                                                  const double* __restrict__ uvec, double* lds) {
+                                                  const double* __restrict__ uvec, double* lds,
+                                                  const double (&xr)[16]) {
   const int tid = threadIdx.x;
   const int w = T.w, r = T.r;
   const double* __restrict__ P = L + T.Loff;
@@ -2432,16 +2447,32 @@ __device__ __forceinline__ void dev_fwd_wide_head(const TopItem& T, const double
     const int k = tid & 127, p = tid >> 7;
     if (k < w) {
       const int lo = (int)(((long long)k * p) >> 3), hi = (int)(((long long)k * (p + 1)) >> 3);
-      const double* Xk = P + k;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int t = lo;
-      for (; t + 3 < hi; t += 4) {
-        s0 += Xk[(long long)t * r] * f[t];
-        s1 += Xk[(long long)(t + 1) * r] * f[t + 1];
-        s2 += Xk[(long long)(t + 2) * r] * f[t + 2];
-        s3 += Xk[(long long)(t + 3) * r] * f[t + 3];
+      if (w <= 128) {
+        // same association as the loop below: groups of four from lo, the remainder into s0
+        const int n4 = (hi - lo) & ~3;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+          if (j < n4) {
+            s0 += xr[j] * f[lo + j];
+            s1 += xr[j + 1] * f[lo + j + 1];
+            s2 += xr[j + 2] * f[lo + j + 2];
+            s3 += xr[j + 3] * f[lo + j + 3];
+          }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j >= n4 && lo + j < hi) s0 += xr[j] * f[lo + j];
+      } else {
+        const double* Xk = P + k;
+        int t = lo;
+        for (; t + 3 < hi; t += 4) {
+          s0 += Xk[(long long)t * r] * f[t];
+          s1 += Xk[(long long)(t + 1) * r] * f[t + 1];
+          s2 += Xk[(long long)(t + 2) * r] * f[t + 2];
+          s3 += Xk[(long long)(t + 3) * r] * f[t + 3];
+        }
+        for (; t < hi; ++t) s0 += Xk[(long long)t * r] * f[t];
       }
-      for (; t < hi; ++t) s0 += Xk[(long long)t * r] * f[t];
       ps[p * w + k] = (s0 + s1) + (s2 + s3);
     }
   }
@@ -2513,9 +2544,8 @@ __device__ __forceinline__ void dev_fwd_wide_slice(const TopItem& T, const doubl
 
 // lds: WIDE_SLICE_ROWS
 __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const double* __restrict__ L,
-                                                   const int* __restrict__ rows, const double* __restrict__ y,
-                                                   double* __restrict__ wpart, double* lds, int* __restrict__ flags,
-                                                   int* __restrict__ info) {
+                                                   const int* __restrict__ rows, const double* __restrict__ ysol,
+                                                   double* __restrict__ wpart, double* lds, int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = T.w, r = T.r;
   const int us = T.a1 - T.a0;
@@ -2536,12 +2566,14 @@ __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const doubl
       lv[cc][q] = (k < w && a < us) ? col[a] : 0.0;
     }
   }
-  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) rwb[a] = (a < us) ? rw[a] : -1;
-  if (T.parent >= 0)
-    top_wait(flags, T.parent, info, 1);
-  else
-    __syncthreads();
-  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) g[a] = (rwb[a] >= 0) ? y[rwb[a]] : 0.0;
+  // the ancestors' solution entries of the slice's rows are polled in the posted copy of the solution (every
+  // backward item posts its entries there): no flag of the parent, no fence - the slice goes ahead as soon as
+  // ITS rows are there, which for all but the first slice of a chain front is long before the parent is done
+  for (int a = tid; a < WIDE_SLICE_ROWS; a += SB) {
+    const int row = (a < us) ? rw[a] : -1;
+    g[a] = (row >= 0) ? poll_f64(ysol + row, info) : 0.0;
+  }
+  (void)rwb;
   __syncthreads();
   // shuffle tree per column (fixed order)
   double s[8];
@@ -2561,14 +2593,14 @@ __device__ __forceinline__ void dev_bwd_wide_slice(const TopItem& T, const doubl
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       const int k = 8 * wave + cc;
-      if (k < w) wpart[T.poff + (long long)sidx * w + k] = s[cc];
+      if (k < w) post_f64(wpart + T.poff + (long long)sidx * w + k, s[cc]);  // polled by the head
     }
   }
 }
 
-// lds: 2 w
+// lds: 2 w + nsl w
 __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double* __restrict__ L,
-                                                  double* __restrict__ y, const double* __restrict__ wpart,
+                                                  double* __restrict__ y, double* __restrict__ wpart,
                                                   double* lds, int* __restrict__ flags, int* __restrict__ hflags,
                                                   int* __restrict__ info, double* __restrict__ ysol) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2589,15 +2621,22 @@ __device__ __forceinline__ void dev_bwd_wide_head(const TopItem& T, const double
     }
   }
   for (int k = tid; k < w; k += SB) zd[k] = y[T.c0 + k] / P[k + (long long)k * r];
-  if (T.nsl > 0)
-    top_wait(hflags, T.s, info, T.nsl);  // the slices waited for the parent
-  else if (T.parent >= 0)
+  // the slices' partial sums are their own flags: posted element by element, polled here (all of them at once,
+  // one or a few per thread), staged in LDS and added in slice order there; the slots go back to the sentinel
+  // for the next solve (single consumer).  A flag hop instead costs the slices a release (3 us: it writes the
+  // L2 back) and the head a second round trip.
+  double* pst = zd + w;  // nsl x w
+  for (int e = tid; e < T.nsl * w; e += SB) {
+    pst[e] = poll_f64(wpart + T.poff + e, info);
+    sent_f64_agent(wpart + T.poff + e);
+  }
+  if (T.nsl == 0 && T.parent >= 0)
     top_wait(flags, T.parent, info, 1);
   else
     __syncthreads();
   for (int k = tid; k < w; k += SB) {
     double s = 0.0;
-    for (int q = 0; q < T.nsl; ++q) s += wpart[T.poff + (long long)q * w + k];
+    for (int q = 0; q < T.nsl; ++q) s += pst[q * w + k];
     v[k] = zd[k] - s;
   }
   __syncthreads();
@@ -2640,11 +2679,13 @@ __global__ __launch_bounds__(SB) void k_fwd_top(const SnDesc* __restrict__ sn, c
   if (T.kind != 2)
     for (int k = threadIdx.x; k < T.w; k += SB) sent_f64(ysol + T.c0 + k);
   if (T.kind != 0) {
+    double xr[16];
+    if (T.kind == 1) dev_fwd_wide_head_prefetch(T, L, xr);
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
       if (ch < T.nchild && T.c_wait[ch]) top_wait(flags, T.c_id[ch], info, T.c_wait[ch]);
     if (T.kind == 1) {
-      dev_fwd_wide_head(T, L, rel, y, uvec, lds);
+      dev_fwd_wide_head(T, L, rel, y, uvec, lds, xr);
       top_publish(hflags, T.s);
     } else {
       dev_fwd_wide_slice(T, L, inv, y, uvec, lds, hflags, info);  // awaits the head after its prefetch
@@ -2684,8 +2725,7 @@ __global__ __launch_bounds__(SB) void k_bwd_top(const SnDesc* __restrict__ sn, c
   else if (T.kind == 2)
     for (int a = T.a0 + threadIdx.x; a < T.a1; a += SB) sent_f64(uvec + T.uoff + a);
   if (T.kind == 2) {
-    dev_bwd_wide_slice(T, L, rows, y, wpart, lds, flags, info);  // awaits the parent after its prefetch
-    top_publish_add(hflags, T.s);
+    dev_bwd_wide_slice(T, L, rows, ysol, wpart, lds, info);  // polls its ancestors' entries after its prefetch
     return;
   }
   if (T.kind == 1) {
