@@ -101,6 +101,11 @@ struct LevelInfo {
   int nA = 0, nC = 0, nD = 0;           // number of (front, part) items
   int panel_threads = 512;              // 16 panel rows per wave
   size_t lds_pivot = 0, lds_panel = 0, lds_schur = 0, lds_asm = 0, lds_solve_max = 0;
+  // single-front level of a dense chain below the dataflow launch: its pivot and panel items as one small dataflow
+  // launch (the panel workgroups follow the posted pivot block) instead of two launches
+  long long mini_off = 0;  // offset (in TopFItems) into d_tfitems
+  int mini_cnt = 0;
+  size_t mini_lds = 0;
 };
 
 // kernel classes for the event-timed profiling mode (option "profile")
@@ -188,6 +193,8 @@ struct PlanState {
   GraphList graphs;
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
+  long long mini_x_off = 0;  // posted pivot blocks of the chain levels' small dataflow launches in d_xarena (doubles) ...
+  size_t mini_x_bytes = 0;   // ... and how many bytes: back to the sentinel with every factorisation
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family
   std::vector<LevelInfo> levels;
   // top of the tree solved in one launch per direction (levels >= top_level)
@@ -225,6 +232,7 @@ struct hipfact_handle : PlanState {
   int plan_cache_max = 4;
   bool spanel_side = false;       // solve panels of the bottom levels on a second stream beside k_factor_top (measured: no gain, the
                                   // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
+  bool chain_fuse = true;         // single-front levels of a dense chain: pivot + panel items as one small dataflow launch
   bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
@@ -266,6 +274,7 @@ struct hipfact_handle : PlanState {
   int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_levels = 1 << 20;  // at most this many levels in the single-launch top-of-tree factorisation (tests)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   int factor_top_post = 64;   // levels with at most this many fronts post the pivot block to polling panel workgroups
   int wide_min_rows = 256;    // fronts with at least this many update rows are solved by several workgroups (0: off; one workgroup streams a panel at ~50 GB/s)
@@ -649,10 +658,11 @@ static int upload_plan(hipfact_handle* h) {
       int mch = 0;
       for (int q = P.level_ptr[lvl - 1]; q < P.level_ptr[lvl]; ++q)
         mch = std::max(mch, P.child_ptr[P.level_sn[q] + 1] - P.child_ptr[P.level_sn[q]]);
-      if (!(li.count <= h->factor_top_max && h->pull_max_children > 0 && mch <= MAXCH)) break;
+      if (!(li.count <= h->factor_top_max && h->pull_max_children > 0 && mch <= MAXCH && P.nlevels - lvl < h->factor_top_levels)) break;
       --lvl;
     }
     h->sp_folded = false;
+    h->mini_x_bytes = 0;
     if (P.nlevels - lvl >= 2 && h->factor_top_max > 0) {
       // fused solve: will there be solve panels (same conditions as below), and are they built inside this launch?
       size_t sp_lds_pre = 0;
@@ -687,6 +697,21 @@ static int upload_plan(hipfact_handle* h) {
           xoff[s] = xsize;
           xsize += wp * wp;
         }
+      // ... and of the single-front levels below the launch that run their pivot and panel items as a small
+      // dataflow launch of their own (dense chains): these slots are put back by a fill per factorisation
+      h->mini_x_off = xsize;
+      for (int l = 0; l < lvl; ++l) {
+        LevelInfo& lm = h->levels[l];
+        lm.mini_cnt = 0;
+        if (!(h->chain_fuse && lm.split && lm.pull && !lm.chain && lm.count == 1)) continue;
+        const int s = P.level_sn[P.level_ptr[l]];
+        if (sn[s].r - sn[s].w < 512 || sn[s].child_end - sn[s].child_begin > MAXCH) continue;
+        const long long wp = (sn[s].w + 15) & ~15;
+        xoff[s] = xsize;
+        xsize += wp * wp;
+        lm.mini_cnt = -1;  // marked; items below
+      }
+      h->mini_x_bytes = (size_t)(xsize - h->mini_x_off) * sizeof(double);
       HCHECK(h, h->d_xarena.ensure(std::max<size_t>((size_t)xsize * sizeof(double), 16)));
       HCHECK(h, hipMemsetAsync(h->d_xarena.p, 0xFF, std::max<size_t>((size_t)xsize * sizeof(double), 16), h->stream));
       for (int l = lvl; l < P.nlevels; ++l) {
@@ -816,6 +841,37 @@ static int upload_plan(hipfact_handle* h) {
       h->ftop_level = lvl;
       h->ftop_count = (int)tf.size();
       h->ftop_lds = lds;
+      for (int l = 0; l < lvl; ++l) {
+        LevelInfo& lm = h->levels[l];
+        if (lm.mini_cnt == 0) continue;
+        const int s = P.level_sn[P.level_ptr[l]];
+        auto mini = [&](int role, int part) {
+          TopFItem t;
+          memset(&t, 0, sizeof(t));
+          t.it.Loff = sn[s].Loff;
+          t.it.Uoff = sn[s].Uoff;
+          t.it.w = sn[s].w;
+          t.it.r = sn[s].r;
+          t.it.part = part;
+          t.it.nchild = sn[s].child_end - sn[s].child_begin;
+          t.it.pd = pulls[s];
+          t.role = role;
+          t.front = s;
+          t.part2 = 0;
+          t.nwait = t.it.nchild;  // the children finished in earlier launches: nothing to wait for
+          for (int k = 0; k < t.nwait; ++k) t.wait_id[k] = P.child_idx[sn[s].child_begin + k];
+          t.crows = 64;
+          t.post = 1;
+          t.xoff = xoff[s];
+          t.target = (sn[s].r - sn[s].w + 63) / 64;
+          return t;
+        };
+        lm.mini_off = (long long)tf.size();
+        tf.push_back(mini(0, 0));
+        for (int b = 0; b < (sn[s].r - sn[s].w + 63) / 64; ++b) tf.push_back(mini(1, b));
+        lm.mini_cnt = (int)(tf.size() - (size_t)lm.mini_off);
+        lm.mini_lds = std::max(lm.lds_pivot, lm.lds_panel);
+      }
       if ((rc = upload(h, h->d_tfitems, tf))) return rc;
     }
   }
@@ -1122,6 +1178,8 @@ static int factor_enqueue(hipfact_handle* h) {
     LAUNCH(PC_GATHER, k_diag_inactive, dim3(nblocks(P.m)), dim3(FB), 0, P.m, h->d_perm.as<int>(), h->d_cmap.as<int>(),
            h->d_diag_target.as<long long>(), h->d_L.as<double>());
   const int lsplit = (h->debug_phases == 15 && !h->no_dataflow) ? std::min(h->ftop_level, P.nlevels) : P.nlevels;
+  if (h->mini_x_bytes > 0 && h->debug_phases == 15 && !h->no_dataflow)
+    HCHECK(h, hipMemsetAsync(h->d_xarena.as<double>() + h->mini_x_off, 0xFF, h->mini_x_bytes, st));
   for (int l = 0; l < lsplit; ++l) {
     const LevelInfo& li = h->levels[l];
     const int* it = h->d_items.as<int>();
@@ -1129,7 +1187,19 @@ static int factor_enqueue(hipfact_handle* h) {
     if (li.nA > 0 && (h->debug_phases & 1) && !pull)
       LAUNCH(PC_FACTOR_A, k_front_assemble, dim3(li.nA), dim3(1024), li.lds_asm, h->d_sn.as<SnDesc>(), it + li.itA, li.nparts,
              h->d_L.as<double>(), h->d_U.as<double>(), h->d_rel.as<int>(), h->d_child.as<int>());
-    if (li.split && h->debug_phases == 15) {
+    if (li.split && h->debug_phases == 15 && li.mini_cnt > 0 && !h->no_dataflow && h->ftop_count > 0) {
+      // dense chain: pivot block and panel of the level's one front in ONE small dataflow launch (the panel
+      // workgroups follow the posted pivot block tile by tile), then its Schur items at three workgroups per CU
+      const FrontItem* fit = h->d_fitems.as<FrontItem>();
+      int* flm = reinterpret_cast<int*>(h->d_L.as<double>() + P.L_size);
+      LAUNCH(PC_FACTOR_B, k_factor_top, dim3(li.mini_cnt), dim3(512), li.mini_lds,
+             h->d_tfitems.as<TopFItem>() + li.mini_off, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(),
+             h->d_inv.as<int>(), h->d_rel.as<int>(), flm, flm + P.nsuper, flm + 2 * P.nsuper, h->d_xarena.as<double>(),
+             nullptr, nullptr, nullptr);
+      if (li.nD > 0)
+        LAUNCH(PC_FACTOR_D, k_front_schur<false>, dim3(li.nD), dim3(FB), li.lds_schur, fit + li.itD, h->d_L.as<double>(),
+               h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), h->d_pullx.as<PullDesc>(), pull);
+    } else if (li.split && h->debug_phases == 15) {
       const FrontItem* fit = h->d_fitems.as<FrontItem>();
 #define SPLIT_LAUNCHES(CH)                                                                                              \
   LAUNCH(PC_FACTOR_B, k_front_pivot<CH>, dim3(li.count), dim3(512), li.lds_pivot, fit + li.itB, h->d_L.as<double>(),   \
@@ -1728,6 +1798,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_DECIDE_LAZY")) h->decide_lazy = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SPANEL_ROOM")) h->spanel_fold_room = atoi(s);
   if (const char* s = getenv("HIPFACT_PANEL_SMALL")) h->panel_small_below = atoi(s);
@@ -2799,6 +2870,16 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->fake_timeouts = (int)value;
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "factor_top_levels")) {
+    h->factor_top_levels = std::max(0, (int)value);
+    invalidate_plans(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "chain_fuse")) {
+    if (h->chain_fuse != (value != 0.0)) invalidate_plans(h);
+    h->chain_fuse = value != 0.0;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "decide_lazy")) {  // 0: every solve graph ends with its own verdict launch
     if (h->decide_lazy != (value != 0.0)) {
       flush_decide(h);
@@ -2929,7 +3010,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

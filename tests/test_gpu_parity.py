@@ -774,6 +774,41 @@ def test_deferred_refinement_verdict(fact):
     fact.set_option("decide_lazy", 1)
 
 
+def test_dense_chain_levels_as_small_dataflow_launches(fact):
+    """Single-front levels of a dense chain below the top-of-tree launch run their pivot and panel items as ONE
+    small dataflow launch (panel workgroups following the posted pivot block) instead of two launches; the sliced
+    fronts of the two-launch solves exchange posted data instead of flags.  Same arithmetic: same bits as the
+    per-level kernels, over repeated factorisations (the posted slots are refilled with the sentinel each time)."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J = synth.uniform_jacobian(3000, 1500, 10, 9)  # dense Schur complement: a chain of single-front levels
+    N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    rng = np.random.default_rng(5)
+    rhs = [rng.standard_normal(N) for _ in range(2)]
+    outs = {}
+    fact.set_option("factor_top_levels", 4)  # most of the chain stays below the top-of-tree launch
+    for fuse in (1, 0):
+        fact.set_option("chain_fuse", fuse)
+        fact.set_option("refine_steps", 0)
+        res = []
+        for rep in range(3):
+            fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            assert (fact.info("chain_levels_fused") >= 3) == bool(fuse)
+            for b in rhs:
+                fact.solve(b)
+                res.append(fact.solution_raw(0, N))
+            assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
+        outs[fuse] = res
+    for a, b_ in zip(outs[1], outs[0]):
+        assert np.array_equal(a, b_)
+    assert np.array_equal(outs[1][0], outs[1][2]) and np.array_equal(outs[1][1], outs[1][5])
+    assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-8
+    fact.set_option("chain_fuse", 1)
+    fact.set_option("refine_steps", 1)
+    fact.set_option("factor_top_levels", 1 << 20)
+
+
 def test_solve_sequence_with_changing_right_hand_sides(fact):
     """The single-launch solve sweeps exchange vectors element by element through slots that the
     opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
