@@ -2,7 +2,7 @@
 entry, panel entries requested, dependency wait over, posted.
 
     python scripts/timeline_tree.py build     # here
-    python scripts/timeline_tree.py run       # on the GPU box (gpurun)
+    python scripts/timeline_tree.py run [workload]   # on the GPU box (gpurun)
 """
 import ctypes as C
 import os
@@ -29,13 +29,13 @@ def build():
     b = s.index("// Solve panels of one front from its factored panel")
     seg = s[a:b]
     # forward
-    seg = seg.replace("  // front row tid: own right-hand side and, per child, which of its update rows lands here", "  TRS(1);\n  // front row tid: own right-hand side and, per child, which of its update rows lands here", 1)
-    seg = seg.replace("  if (tid < r) f[tid] = f0;\n  __syncthreads();", "  if (tid < r) f[tid] = f0;\n  __syncthreads();\n  TRS(2);", 1)
-    seg = seg.replace("      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);\n  }\n}", "      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);\n  }\n  TRS(3);\n}", 1)
+    seg = seg.replace("  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here", "  TRS(1);\n  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here", 1)
+    seg = seg.replace("  if (tid < rl) f[tid] = f0;\n  __syncthreads();", "  if (tid < rl) f[tid] = f0;\n  __syncthreads();\n  TRS(2);", 1)
+    seg = seg.replace("      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n}", "      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n  TRS(3);\n}", 1)
     # backward
-    seg = seg.replace("  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;", "  TRS(1);\n  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;", 1)
-    seg = seg.replace("  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));\n  __syncthreads();", "  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));\n  __syncthreads();\n  TRS(2);", 1)
-    seg = seg.replace("    post_f64(ysol + T.c0 + tid, s2);\n  }\n}", "    post_f64(ysol + T.c0 + tid, s2);\n  }\n  TRS(3);\n}", 1)
+    seg = seg.replace("  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", "  TRS(1);\n  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", 1)
+    seg = seg.replace("  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();", "  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();\n  TRS(2);", 1)
+    seg = seg.replace("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n}", "      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n  TRS(3);\n}", 1)
     seg = seg.replace("  const int par = *epoch & 1;", "  TRS(0);\n  const int par = *epoch & 1;", 1)
     assert seg.count("TRS(") == 7, seg.count("TRS(")
     s = s[:a] + seg + s[b:]
@@ -61,7 +61,7 @@ def run():
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
-    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    J, N, cp, ri, vx, b = make_problem(sys.argv[2] if len(sys.argv) > 2 else "banded_n1e5_m5e4", 0)
     f = HipFact(device=0)
     f.set_option("use_graph", 0)
     f.set_option("refine_steps", 0)
@@ -73,11 +73,17 @@ def run():
     out = np.zeros(NB * 8, dtype=np.int64)
     lib.hipfact_debug_trace_tree.argtypes = [C.c_void_p]
     assert lib.hipfact_debug_trace_tree(out.ctypes.data_as(C.c_void_p)) == 0
-    nf = int(f.info("nsuper"))
+    nf = int(f.info("solve_items"))
     t = out.reshape(NB, 8)[: 2 * nf, :4].astype(np.float64)
     t = (t - t[:, 0].min()) / 100.0  # 100 MHz
     P = Plan(lib, N, cp, ri, vx)
-    lev = P.sn_level[P.level_sn]  # level of the item at each forward position
+    # level of the item at each forward position: one item per front, ceil(u / 256) row slices for fronts of more than 1024 rows
+    lev = []
+    for s_ in P.level_sn:
+        r_, w_ = int(P.sn_r[s_]), int(P.sn_c0[s_ + 1] - P.sn_c0[s_])
+        lev += [int(P.sn_level[s_])] * (1 if r_ <= 1024 else -(-(r_ - w_) // 256))
+    lev = np.array(lev)
+    assert len(lev) == nf
     print("# fused solve launch, us since the first workgroup started.  per level: workgroups, entry (min..max), waited (max), posted (max)")
     for name, sl, levels in (("forward", slice(0, nf), lev), ("backward", slice(nf, 2 * nf), lev[::-1])):
         tt = t[sl]

@@ -102,6 +102,13 @@ struct SolveItem {
   int c_invoff[MAXCH];       // children's inverse relative indices (which update row lands on front row i)
   long long Loff;            // the front's panel (source of the solve panels)
   int xbegin, xend;          // children beyond the first MAXCH: entries [xbegin, xend) of the overflow lists
+  // A front with more than 1024 rows is several items (slices), each with thread-major copies of ITS rows of S:
+  // slice 0 the pivot rows and the update rows [0, a1), slice sl > 0 the update rows [a0, a1).  Forward: every
+  // slice forms the front's f_top itself and posts its rows of [x^; u]; backward: the slices sl > 0 post their
+  // w partial sums (they only need their ancestors' entries: long before the parent is done), slice 0 polls and
+  // adds them in slice order.  One item per front otherwise (a0 = 0, a1 = r - w, nsl = 1).
+  int a0, a1, sl, nsl;
+  long long poff;            // the front's (nsl - 1) x w partial sums in the partial-sum arena
 };
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 

@@ -213,7 +213,8 @@ struct PlanState {
   bool fused_solve = false;
   size_t sp_lds = 0;
   double sp_bytes = 0;
-  DevBuf d_SPf, d_SPb, d_sitems, d_xhat, d_sxuoff, d_sxinvoff, d_epoch;
+  DevBuf d_SPf, d_SPb, d_sitems, d_xhat, d_sxuoff, d_sxinvoff, d_epoch, d_spart;
+  int n_sitems = 0;  // items of the fused solve launch: one per front, row slices for fronts of more than 1024 rows
 
   PlanState() = default;
   PlanState(PlanState&&) = default;
@@ -233,6 +234,7 @@ struct hipfact_handle : PlanState {
   bool spanel_side = false;       // solve panels of the bottom levels on a second stream beside k_factor_top (measured: no gain, the
                                   // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
   bool chain_fuse = true;         // single-front levels of a dense chain: pivot + panel items as one small dataflow launch
+  bool solve_slices = true;       // fused solve: fronts whose panel share does not fit the registers of one item are row-sliced
   bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
@@ -647,6 +649,45 @@ static int upload_plan(hipfact_handle* h) {
     }
   if ((rc = upload(h, h->d_items, items))) return rc;
   if ((rc = upload(h, h->d_fitems, fitems))) return rc;
+  // Items of the fused solve launch (level order).  An item keeps its share of the solve panel in registers across
+  // its dependency wait: SOLVE_PREFETCH entries per thread, i.e. rows x w <= 1024 x SOLVE_PREFETCH per item (what
+  // does not fit is loaded behind the wait, on the critical path of the tree: a memory round trip per entry).
+  // A front with more rows than that is cut into row slices (slice 0: the pivot rows and the first update rows;
+  // update rows in multiples of 16), see SolveItem.
+  auto slice_rows = [&](int w2) {  // most rows an item of a front of width w2 can hold
+    const int fwd = 1024 / ((w2 + SOLVE_PREFETCH - 1) / SOLVE_PREFETCH);  // Ef = ceil(w / floor(1024 / rows)) <= PREFETCH
+    const int bwd = SOLVE_PREFETCH * std::max(1, 1024 / w2);              // Eb = ceil(rows / floor(1024 / w)) <= PREFETCH
+    return std::max(w2 + 16, std::min({fwd, bwd, 1024}));
+  };
+  std::vector<int> it_front, it_sl, it_nsl, it_a0, it_a1, first_item(ns, 0);
+  for (int q = 0; q < ns; ++q) {
+    const int s2 = P.level_sn[q];
+    const int w2 = std::max(1, sn[s2].w), u2 = sn[s2].r - sn[s2].w;
+    const int cap = slice_rows(w2);
+    first_item[s2] = (int)it_front.size();
+    std::vector<std::pair<int, int>> cuts;
+    // sliced when it must be (more than 1024 rows) or when more than half of an item's entries would be loaded behind
+    // its wait (config 3's fronts of 600-1000 rows x 126 columns: 28 us per level); fronts a little over the register
+    // capacity stay whole - a second item and the exchange of partial sums cost more than 18 loads (config 4)
+    const int q1 = std::max(1, 1024 / std::max(1, sn[s2].r));
+    const bool whole = sn[s2].r <= 1024 && (w2 + q1 - 1) / q1 <= 2 * SOLVE_PREFETCH;
+    if (sn[s2].r <= cap || whole || !h->solve_slices) {
+      cuts.push_back({0, u2});
+    } else {
+      // (an item stages the pivot rows and its update rows, one per thread: w + rows <= 1024)
+      const int first = std::max(16, (cap - w2) & ~15), rest = std::max(16, std::min(cap, 1024 - w2) & ~15);
+      cuts.push_back({0, std::min(u2, first)});
+      for (int a = cuts.back().second; a < u2; a += rest) cuts.push_back({a, std::min(u2, a + rest)});
+    }
+    for (size_t sl = 0; sl < cuts.size(); ++sl) {
+      it_front.push_back(s2);
+      it_sl.push_back((int)sl);
+      it_nsl.push_back((int)cuts.size());
+      it_a0.push_back(cuts[sl].first);
+      it_a1.push_back(cuts[sl].second);
+    }
+  }
+  const int nit = (int)it_front.size();
   {
     // top-of-tree factorisation in one launch: the last levels, as long as every one of them is
     // narrow and can pull its extend-add (no front with more than MAXCH children)
@@ -670,7 +711,7 @@ static int upload_plan(hipfact_handle* h) {
       {
         int wmax = 1;
         for (int s2 = 0; s2 < ns; ++s2) {
-          fold = fold && sn[s2].r <= 1024 && sn[s2].w >= 1;
+          fold = fold && sn[s2].w >= 1 && (h->solve_slices || sn[s2].r <= 1024);
           wmax = std::max(wmax, sn[s2].w);
         }
         sp_lds_pre = solve_panel_lds(wmax);
@@ -789,16 +830,16 @@ static int upload_plan(hipfact_handle* h) {
         // Fronts in level order: those below the launch are final already, a front of the launch can follow the
         // panel items of a later level (or wait a moment for its own).  What is left goes behind the root.
         std::vector<TopFItem> out;
-        out.reserve(tf.size() + ns);
+        out.reserve(tf.size() + nit);
         int qnext = 0;
         auto filler = [&](int q) {
-          const int s = P.level_sn[q];
+          const int s = it_front[q];
           TopFItem t;
           memset(&t, 0, sizeof(t));
           t.it.Loff = sn[s].Loff;
           t.it.w = sn[s].w;
           t.it.r = sn[s].r;
-          t.it.part = q;  // index of the front's SolveItem (level order)
+          t.it.part = q;  // index of the SolveItem (level order; a sliced front has several)
           t.role = 3;
           t.front = s;
           t.part2 = -1;
@@ -811,29 +852,27 @@ static int upload_plan(hipfact_handle* h) {
         };
         // a front of the launch without update rows (the root) writes its solve panel in its pivot item
         std::vector<char> own(ns, 0);
-        std::vector<int> pos(ns, 0);
-        for (int q = 0; q < ns; ++q) pos[P.level_sn[q]] = q;
         for (TopFItem& t : tf)
           if (t.role == 0 && t.it.r == t.it.w) {
-            t.sidx = pos[t.front] + 1;
+            t.sidx = first_item[t.front] + 1;
             own[t.front] = 1;
           }
         auto skip_own = [&] {
-          while (qnext < ns && own[P.level_sn[qnext]]) ++qnext;
+          while (qnext < nit && own[it_front[qnext]]) ++qnext;
         };
         size_t from = 0;
         for (int l = lvl; l < P.nlevels; ++l) {
           const size_t mid = panel_end[l - lvl], to = level_end[l - lvl];
           out.insert(out.end(), tf.begin() + from, tf.begin() + mid);
           long long room = (long long)h->spanel_fold_room - (long long)(mid - from);
-          for (skip_own(); room > 0 && qnext < ns && P.sn_level[P.level_sn[qnext]] <= l; skip_own()) {
+          for (skip_own(); room > 0 && qnext < nit && P.sn_level[it_front[qnext]] <= l; skip_own()) {
             out.push_back(filler(qnext++));
             --room;
           }
           out.insert(out.end(), tf.begin() + mid, tf.begin() + to);
           from = to;
         }
-        for (skip_own(); qnext < ns; skip_own()) out.push_back(filler(qnext++));
+        for (skip_own(); qnext < nit; skip_own()) out.push_back(filler(qnext++));
         tf.swap(out);
         lds = std::max(lds, sp_lds_pre);
         h->sp_folded = true;
@@ -975,19 +1014,22 @@ static int upload_plan(hipfact_handle* h) {
     HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * ns * sizeof(int), h->stream));
   }
   {
-    // fused solve launch: every front as a SolveItem, children before parents (level order)
+    // fused solve launch: every front (or row slice of a big front) as a SolveItem, children before parents
     h->fused_solve = false;
+    h->n_sitems = 0;
     bool ok = h->solve_fused && ns > 0;
-    for (int s2 = 0; s2 < ns && ok; ++s2) ok = sn[s2].r <= 1024 && sn[s2].w >= 1;
+    for (int s2 = 0; s2 < ns && ok; ++s2) ok = sn[s2].w >= 1 && (h->solve_slices || sn[s2].r <= 1024);
     if (ok) {
       std::vector<SolveItem> si;
       std::vector<long long> xuoff;  // children beyond the first MAXCH of a front
       std::vector<int> xinvoff;
-      si.reserve(ns);
-      long long spf = 0, spb = 0;
+      std::vector<int> fx0(ns, 0), fx1(ns, 0);
+      std::vector<long long> fpoff(ns, 0);
+      si.reserve(nit);
+      long long spf = 0, spb = 0, spart = 0;
       int wmax = 1;
-      for (int q = 0; q < ns; ++q) {
-        const int s2 = P.level_sn[q];
+      for (int q = 0; q < nit; ++q) {
+        const int s2 = it_front[q], sl = it_sl[q], nsl = it_nsl[q];
         SolveItem T;
         memset(&T, 0, sizeof(T));
         T.c0 = sn[s2].c0;
@@ -998,25 +1040,37 @@ static int upload_plan(hipfact_handle* h) {
         T.Loff = sn[s2].Loff;
         const int nch = sn[s2].child_end - sn[s2].child_begin;
         T.nchild = std::min(nch, MAXCH);
-        T.xbegin = (int)xuoff.size();
+        if (sl == 0) {
+          fx0[s2] = (int)xuoff.size();
+          fpoff[s2] = spart;
+          spart += (long long)(nsl - 1) * T.w;
+        }
         for (int k = 0; k < nch; ++k) {
           const int ch = P.child_idx[sn[s2].child_begin + k];
           if (k < MAXCH) {
             T.c_uoff[k] = sn[ch].uoff;
             T.c_invoff[k] = sn[ch].pad1;
-          } else {
+          } else if (sl == 0) {
             xuoff.push_back(sn[ch].uoff);
             xinvoff.push_back(sn[ch].pad1);
           }
         }
-        T.xend = (int)xuoff.size();
-        T.Qf = std::max(1, std::min(T.w, 1024 / T.r));
+        if (sl == 0) fx1[s2] = (int)xuoff.size();
+        T.xbegin = fx0[s2];
+        T.xend = fx1[s2];
+        T.sl = sl;
+        T.nsl = nsl;
+        T.poff = fpoff[s2];
+        T.a0 = it_a0[q];
+        T.a1 = it_a1[q];
+        const int ro = (sl == 0 ? T.w : 0) + (T.a1 - T.a0);  // rows of the item's copies of S
+        T.Qf = std::max(1, std::min(T.w, 1024 / ro));
         T.Ef = (T.w + T.Qf - 1) / T.Qf;
-        T.Pb = std::max(1, std::min(T.r, 1024 / T.w));
-        T.Eb = (T.r + T.Pb - 1) / T.Pb;
+        T.Pb = std::max(1, std::min(ro, 1024 / T.w));
+        T.Eb = (ro + T.Pb - 1) / T.Pb;
         T.spf = spf;
         T.spb = spb;
-        spf += ((long long)T.Ef * T.r * T.Qf + 1) & ~1LL;
+        spf += ((long long)T.Ef * ro * T.Qf + 1) & ~1LL;
         spb += ((long long)T.Eb * T.w * T.Pb + 1) & ~1LL;
         wmax = std::max(wmax, T.w);
         si.push_back(T);
@@ -1032,9 +1086,13 @@ static int upload_plan(hipfact_handle* h) {
         HCHECK(h, hipMemsetAsync(h->d_SPb.p, 0, std::max<size_t>((size_t)spb * sizeof(double), 16), h->stream));
         HCHECK(h, h->d_xhat.ensure(std::max<size_t>((size_t)P.m * sizeof(double), 16)));
         HCHECK(h, hipMemsetAsync(h->d_xhat.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), h->stream));
+        // partial sums of the backward items of sliced fronts: polled, sentinel between solves
+        HCHECK(h, h->d_spart.ensure(std::max<size_t>((size_t)spart * sizeof(double), 16)));
+        HCHECK(h, hipMemsetAsync(h->d_spart.p, 0xFF, h->d_spart.bytes, h->stream));
         HCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_solve_panels),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->fused_solve = true;
+        h->n_sitems = nit;
         h->sp_bytes = (double)(spf + spb) * sizeof(double);
       }
     }
@@ -1228,7 +1286,8 @@ static int factor_enqueue(hipfact_handle* h) {
   // launch is bound by the tree's critical path with most of the chip idle - their panels (most of the bytes)
   // are built beside it on a second stream; the fronts of the top levels follow behind it.
   int sp_done = 0;
-  if (h->fused_solve && !h->no_dataflow && h->spanel_side && lsplit < P.nlevels && lsplit > 0 && !h->prof.on && h->side) {
+  if (h->fused_solve && !h->no_dataflow && h->spanel_side && lsplit < P.nlevels && lsplit > 0 && !h->prof.on && h->side &&
+      h->n_sitems == P.nsuper) {
     sp_done = P.level_ptr[lsplit];
     HCHECK(h, hipEventRecord(h->ev_fork, st));
     HCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -1246,8 +1305,8 @@ static int factor_enqueue(hipfact_handle* h) {
   }
   if (h->fused_solve && !h->no_dataflow && !(h->sp_folded && lsplit < P.nlevels)) {
     if (sp_done > 0) HCHECK(h, hipStreamWaitEvent(st, h->ev_join, 0));
-    if (P.nsuper > sp_done)
-      LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(P.nsuper - sp_done), dim3(SPB), h->sp_lds,
+    if (h->n_sitems > sp_done)
+      LAUNCH(PC_SPANEL, k_build_solve_panels, dim3(h->n_sitems - sp_done), dim3(SPB), h->sp_lds,
              h->d_sitems.as<SolveItem>() + sp_done, h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
   }
   HCHECK(h, hipGetLastError());
@@ -1285,6 +1344,7 @@ static int reset_dataflow_state(hipfact_handle* h) {
   if (h->d_ysol.p) HCHECK(h, hipMemsetAsync(h->d_ysol.p, 0xFF, std::max<size_t>((size_t)2 * P.m * sizeof(double), 16), st));
   if (h->d_xhat.p) HCHECK(h, hipMemsetAsync(h->d_xhat.p, 0xFF, std::max<size_t>((size_t)P.m * sizeof(double), 16), st));
   if (h->d_wpart.p) HCHECK(h, hipMemsetAsync(h->d_wpart.p, 0xFF, h->d_wpart.bytes, st));
+  if (h->d_spart.p) HCHECK(h, hipMemsetAsync(h->d_spart.p, 0xFF, h->d_spart.bytes, st));
   if (h->d_flags.p) HCHECK(h, hipMemsetAsync(h->d_flags.p, 0, (size_t)4 * P.nsuper * sizeof(int), st));
   HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
   HCHECK(h, hipMemsetAsync(h->d_ctl.p, 0, sizeof(RefineCtl), st));
@@ -1356,12 +1416,12 @@ static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs =
   const Plan& P = h->plan;
   if (h->fused_solve && !h->no_dataflow) {
     // (one workgroup more than items: it delivers the deferred verdict of the previous solve, if any)
-    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * P.nsuper + 1), dim3(ST), 0, h->d_sitems.as<SolveItem>(), P.nsuper,
+    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * h->n_sitems + 1), dim3(ST), 0, h->d_sitems.as<SolveItem>(), h->n_sitems,
            h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
            h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_xhat.as<double>(), h->d_uvec.as<double>(), h->d_ysol.as<double>(), P.m, h->d_epoch.as<int>(),
            h->d_info.as<int>(), skip, rhs ? *rhs : RhsIn{nullptr, nullptr, nullptr, nullptr, SaddleMaps{nullptr, nullptr, nullptr, 0}, nullptr},
-           decide_in(h));
+           decide_in(h), h->d_spart.as<double>());
     return;
   }
   const int ltop = h->no_dataflow ? P.nlevels : std::min(h->top_level, P.nlevels);
@@ -1798,6 +1858,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_SOLVE_SLICES")) h->solve_slices = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_DECIDE_LAZY")) h->decide_lazy = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SPANEL_ROOM")) h->spanel_fold_room = atoi(s);
@@ -2875,6 +2936,11 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     invalidate_plans(h);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "solve_slices")) {  // 0: one item per front in the fused solve launch (fronts of up to 1024 rows only)
+    if (h->solve_slices != (value != 0.0)) invalidate_plans(h);
+    h->solve_slices = value != 0.0;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "chain_fuse")) {
     if (h->chain_fuse != (value != 0.0)) invalidate_plans(h);
     h->chain_fuse = value != 0.0;
@@ -3010,7 +3076,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

@@ -2926,19 +2926,26 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
                                               double* __restrict__ ysol, double* lds, int* __restrict__ info,
                                               const RhsIn& R) {
   const int tid = threadIdx.x;
-  const int w = T.w, r = T.r, Q = T.Qf, E = T.Ef;
-  const int TS = r * Q;
+  const int w = T.w, Q = T.Qf, E = T.Ef;
+  // rows of this item: the front's pivot rows (always staged: the product's input) and its update rows
+  // [a0, a1); the item's panel copy holds the rows it puts out: the pivot rows only in slice 0
+  const int a0 = T.a0, nu = T.a1 - T.a0;
+  const int top = (T.sl == 0) ? w : 0;
+  const int ro = top + nu;  // output rows
+  const int rl = w + nu;    // staged rows
+  const int TS = ro * Q;
   const bool active = tid < TS;
-  const int i = active ? tid % r : 0, q = active ? tid / r : 0;
-  double* f = lds;          // r
-  double* part = lds + r;   // Q * r <= 1024
+  const int q = active ? tid / ro : 0;
+  double* f = lds;          // rl
+  double* part = lds + rl;  // Q * ro <= 1024
   // the copy of the solution the PREVIOUS launch exchanged through: back to the sentinel
   if (tid < w) sent_f64(ysol + T.c0 + tid);
   const double* __restrict__ sp = SPf + T.spf + tid;
   double pv[SOLVE_PREFETCH];
 #pragma unroll
   for (int e = 0; e < SOLVE_PREFETCH; ++e) pv[e] = (active && e < E) ? sp[(long long)e * TS] : 0.0;
-  // front row tid: own right-hand side and, per child, which of its update rows lands here
+  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here
+  const int fr = tid + (tid >= w ? a0 : 0);
   double f0 = 0.0;
   if (R.Ar_ptr) {
     // the front's own rows of t, formed here instead of by a launch in front of this one (every item does this
@@ -2954,7 +2961,7 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
   }
   int iv[MAXCH];
 #pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < r) ? inv[T.c_invoff[ch] + tid] : -1;
+  for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < T.nchild && tid < rl) ? inv[T.c_invoff[ch] + fr] : -1;
   {
     // all children's entries of this row requested at once (several children usually reach the same
     // separator rows: one round trip instead of one per child), re-polled only where still pending,
@@ -2973,10 +2980,10 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
       }
   }
   for (int x = T.xbegin; x < T.xend; ++x) {  // fronts with more than MAXCH children (rare)
-    const int ia = (tid < r) ? inv[xinvoff[x] + tid] : -1;
+    const int ia = (tid < rl) ? inv[xinvoff[x] + fr] : -1;
     if (ia >= 0) f0 += poll_f64(uvec + xuoff[x] + ia, info);
   }
-  if (tid < r) f[tid] = f0;
+  if (tid < rl) f[tid] = f0;
   __syncthreads();
   double acc = 0.0;
 #pragma unroll
@@ -2986,57 +2993,90 @@ __device__ __forceinline__ void dev_solve_fwd(const SolveItem& T, const double* 
     if (active) acc = fma(sp[(long long)e * TS], f[min(q + Q * e, w - 1)], acc);
   if (active) part[tid] = acc;
   __syncthreads();
-  if (tid < r) {
+  if (tid < ro) {
     double s2 = 0.0;
-    for (int qq = 0; qq < Q; ++qq) s2 += part[qq * r + tid];
-    if (tid < w)
+    for (int qq = 0; qq < Q; ++qq) s2 += part[qq * ro + tid];
+    if (tid < top) {
       post_f64(xhat + T.c0 + tid, s2);  // X has a unit diagonal: f[tid] is inside the product
-    else
-      post_f64(uvec + T.uoff + (tid - w), f[tid] + s2);
+    } else {
+      const int j = tid - top;  // update row a0 + j of the front, staged at f[w + j]
+      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);
+    }
   }
 }
 
 __device__ __forceinline__ void dev_solve_bwd(const SolveItem& T, const double* __restrict__ SPb,
                                               const int* __restrict__ rows, double* __restrict__ y,
                                               double* __restrict__ xhat, double* __restrict__ uvec,
-                                              double* __restrict__ ysol, double* lds, int* __restrict__ info) {
+                                              double* __restrict__ ysol, double* __restrict__ spart, double* lds,
+                                              int* __restrict__ info) {
   const int tid = threadIdx.x;
-  const int w = T.w, r = T.r, P = T.Pb, E = T.Eb;
+  const int w = T.w, P = T.Pb, E = T.Eb;
+  const int a0 = T.a0, nu = T.a1 - T.a0;
+  const int top = (T.sl == 0) ? w : 0;
+  const int ro = top + nu;  // rows of this item's panel copy: [pivot rows (slice 0);] update rows [a0, a1)
   const int TS = w * P;
   const bool active = tid < TS;
-  const int k = active ? tid % w : 0, p = active ? tid / w : 0;
-  (void)k;
-  double* tv = lds;         // r: [x^; g]
-  double* part = lds + r;   // P * w <= 1024
+  const int p = active ? tid / w : 0;
+  double* tv = lds;         // ro: [x^; g]
+  double* part = lds + ro;  // P * w <= 1024
   const double* __restrict__ sp = SPb + T.spb + tid;
   double pv[SOLVE_PREFETCH];
 #pragma unroll
   for (int e = 0; e < SOLVE_PREFETCH; ++e) pv[e] = (active && e < E) ? sp[(long long)e * TS] : 0.0;
-  const int myrow = (tid >= w && tid < r) ? rows[T.rowoff + tid] : -1;
+  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;
   // x^ from the forward item of this front (the root turns around here), the ancestors' solution
   // entries from their backward items: polled one by one, no flag, no fence
-  if (tid < w) {
+  if (tid < top) {
     tv[tid] = poll_f64(xhat + T.c0 + tid, info);
     sent_f64_agent(xhat + T.c0 + tid);  // single consumer: slot ready for the next solve
   } else if (myrow >= 0) {
     tv[tid] = poll_f64(ysol + myrow, info);
   }
   // the parent's forward item consumed this front's update vector long ago (it precedes the root's turn)
-  if (tid >= w && tid < r) sent_f64_agent(uvec + T.uoff + (tid - w));
+  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));
   __syncthreads();
   double acc = 0.0;
 #pragma unroll
   for (int e = 0; e < SOLVE_PREFETCH; ++e)
-    if (e < E) acc = fma(pv[e], tv[min(p + P * e, r - 1)], acc);  // entries beyond row r - 1 are stored as zeros
+    if (e < E) acc = fma(pv[e], tv[min(p + P * e, ro - 1)], acc);  // entries beyond row ro - 1 are stored as zeros
   for (int e = SOLVE_PREFETCH; e < E; ++e)
-    if (active) acc = fma(sp[(long long)e * TS], tv[min(p + P * e, r - 1)], acc);
+    if (active) acc = fma(sp[(long long)e * TS], tv[min(p + P * e, ro - 1)], acc);
   if (active) part[tid] = acc;
   __syncthreads();
   if (tid < w) {
     double s2 = 0.0;
     for (int pp = 0; pp < P; ++pp) s2 += part[pp * w + tid];
-    y[T.c0 + tid] = s2;
-    post_f64(ysol + T.c0 + tid, s2);
+    if (T.sl > 0) {
+      post_f64(spart + T.poff + (long long)(T.sl - 1) * w + tid, s2);  // polled by slice 0 of the front
+    } else {
+      // the other slices' partial sums (they only waited for their ancestors' entries: usually there already),
+      // added in slice order; the slots go back to the sentinel (single consumer)
+      // (requested sixteen at a time: a loop of polls would pay one memory round trip per slice)
+      for (int s0 = 1; s0 < T.nsl; s0 += 16) {
+        unsigned long long bits[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int s = s0 + j;
+          bits[j] = s < T.nsl ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(
+                                                      spart + T.poff + (long long)(s - 1) * w + tid),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int s = s0 + j;
+          if (s < T.nsl) {
+            double* slot = spart + T.poff + (long long)(s - 1) * w + tid;
+            if (bits[j] == SOLVE_SENT) bits[j] = (unsigned long long)__double_as_longlong(poll_f64(slot, info));
+            s2 += __longlong_as_double((long long)bits[j]);
+            sent_f64_agent(slot);
+          }
+        }
+      }
+      y[T.c0 + tid] = s2;
+      post_f64(ysol + T.c0 + tid, s2);
+    }
   }
 }
 
@@ -3048,7 +3088,8 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
                                                    double* __restrict__ xhat,
                                                    double* __restrict__ uvec, double* __restrict__ ysol2, int m,
                                                    const int* __restrict__ epoch, int* __restrict__ info,
-                                                   const int* __restrict__ skip, RhsIn R, DecideIn D) {
+                                                   const int* __restrict__ skip, RhsIn R, DecideIn D,
+                                                   double* __restrict__ spart) {
   __shared__ __attribute__((aligned(16))) double lds[2 * 1024 + 8];
   const int b = blockIdx.x;
   if (b == 2 * nf) {
@@ -3065,7 +3106,7 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
     dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info, R);
   } else {
     const SolveItem& T = items[2 * nf - 1 - b];
-    dev_solve_bwd(T, SPb, rows, y, xhat, uvec, ysol2 + (size_t)par * m, lds, info);
+    dev_solve_bwd(T, SPb, rows, y, xhat, uvec, ysol2 + (size_t)par * m, spart, lds, info);
   }
 }
 
@@ -3078,7 +3119,11 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
 constexpr int SPB = 512;
 __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const double* __restrict__ L,
                                                       double* __restrict__ SPf, double* __restrict__ SPb, double* lds) {
-  const int w = T.w, r = T.r, u = r - w;
+  const int w = T.w, r = T.r;
+  // the item's rows of S: the pivot rows (slice 0 only) and the update rows [ua, ua + u) of the front
+  const int ua = T.a0, u = T.a1 - T.a0;
+  const int top = (T.sl == 0) ? w : 0;
+  const int ro = top + u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int nbk = (w + 15) >> 4, wp = nbk << 4;
@@ -3090,14 +3135,14 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
   // where column k of the forward copy and row i of the backward copy start (integer divisions are ~40
   // instructions each on this hardware: once per column / row instead of once per element)
   long long* offF = reinterpret_cast<long long*>(dinv + wp + (SPB / 64) * (16 * 17));  // wp
-  long long* offB = offF + wp;                                                          // r
+  long long* offB = offF + wp;                                                          // ro
   // the first strip of this wave: requested before X is staged, so that both arrive together
   const int nstrip = (u + 15) >> 4;
   double av[32];
   {
     const int a0 = wave << 4;
     const bool rowok = wave < nstrip && a0 + li < u;
-    const double* __restrict__ Lr = Pn + w + a0 + li;
+    const double* __restrict__ Lr = Pn + w + ua + a0 + li;
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
       const int j = 4 * t + lk;
@@ -3126,9 +3171,9 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
   }
   for (int k = tid; k < wp; k += SPB) dinv[k] = (k < w) ? 1.0 / Pn[k + (long long)k * r] : 1.0;
   const int Qf = T.Qf, Pb = T.Pb;
-  const long long TSf = (long long)r * Qf, TSb = (long long)w * Pb;
-  for (int k = tid; k < wp; k += SPB) offF[k] = (long long)(k / Qf) * TSf + (long long)(k % Qf) * r;
-  for (int i = tid; i < r; i += SPB) offB[i] = (long long)(i / Pb) * TSb + (long long)(i % Pb) * w;
+  const long long TSf = (long long)ro * Qf, TSb = (long long)w * Pb;
+  for (int k = tid; k < wp; k += SPB) offF[k] = (long long)(k / Qf) * TSf + (long long)(k % Qf) * ro;
+  for (int i = tid; i < ro; i += SPB) offB[i] = (long long)(i / Pb) * TSb + (long long)(i % Pb) * w;
   __syncthreads();
   double* __restrict__ sf = SPf + T.spf;
   double* __restrict__ sb = SPb + T.spb;
@@ -3153,7 +3198,7 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
     {
       const int an = (st + SPB / 64) << 4;
       const bool rowok = st + SPB / 64 < nstrip && an + li < u;
-      const double* __restrict__ Lr = Pn + w + an + li;
+      const double* __restrict__ Lr = Pn + w + ua + an + li;
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         const int j = 4 * t + lk;
@@ -3167,7 +3212,7 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
       if (kt >= nbk) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = lk + 4 * q, k = 16 * kt + li, i = w + a0 + row;
+        const int row = lk + 4 * q, k = 16 * kt + li, i = top + a0 + row;
         tile[row * 17 + li] = -acc[kt][q];
         if (a0 + row < u && k < w) sb[offB[i] + k] = -acc[kt][q];
       }
@@ -3176,7 +3221,7 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = li, col = lk + 4 * q, k = 16 * kt + col, i = w + a0 + row;
+        const int row = li, col = lk + 4 * q, k = 16 * kt + col, i = top + a0 + row;
         if (a0 + row < u && k < w) sf[offF[k] + i] = tile[row * 17 + col];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -3185,6 +3230,7 @@ __device__ __forceinline__ void dev_build_solve_panel(const SolveItem& T, const 
   }
   // pivot rows: S[i, k] = X[i, k] (lower triangle); backward copy divided by d_i.  Two passes so that each
   // copy is written along its contiguous direction (rows i forward, columns k backward).
+  if (top == 0) return;  // (the pivot rows belong to slice 0)
   for (int k = wave; k < w; k += SPB / 64)
     for (int i = k + lane; i < w; i += 64) sf[offF[k] + i] = X[i + k * ldx];
   for (int i = wave; i < w; i += SPB / 64) {

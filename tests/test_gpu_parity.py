@@ -596,13 +596,21 @@ def test_wide_fronts_solved_by_several_workgroups(fact):
         assert fact.info("solve_timeouts") == 0
         assert scaled_residual(K, outs[-1], b) <= 1e-10
     assert rel_err(outs[1], outs[0]) <= 1e-10
-    # fronts of more than 1024 rows do not qualify for the fused launch: the request falls back to these kernels
+    # in the fused launch a front of more than 1024 rows is several items (row slices with their own copies of
+    # their rows of the solve panel; the backward items of the slices post partial sums that slice 0 adds up):
+    # repeated solves and a refactorisation in between (the polled slots must all be back at the sentinel)
     fact.set_option("solve_fused", 1)
-    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
-    assert fact.info("fused_solve") == (1 if fact.info("max_r") <= 1024 else 0)
-    for _ in range(2):
-        fact.solve(b)
-    assert rel_err(fact.solution_raw(0, N), outs[0]) <= 1e-10 and fact.info("solve_timeouts") == 0
+    for rep in range(2):
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("fused_solve") == 1
+        for _ in range(3):
+            fact.solve(b)
+            z = fact.solution_raw(0, N)
+            assert rel_err(z, outs[0]) <= 1e-10 and fact.info("solve_timeouts") == 0
+            assert scaled_residual(K, z, b) <= 1e-10
+        b2 = np.random.default_rng(6 + rep).standard_normal(N)
+        fact.solve(b2)
+        assert scaled_residual(K, fact.solution_raw(0, N), b2) <= 1e-10
 
 
 def test_top_of_tree_solve_variants_agree_bitwise(fact):
