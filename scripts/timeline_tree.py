@@ -77,13 +77,18 @@ def run():
     t = out.reshape(NB, 8)[: 2 * nf, :4].astype(np.float64)
     t = (t - t[:, 0].min()) / 100.0  # 100 MHz
     P = Plan(lib, N, cp, ri, vx)
-    # level of the item at each forward position: one item per front, ceil(u / 256) row slices for fronts of more than 1024 rows
-    lev = []
-    for s_ in P.level_sn:
-        r_, w_ = int(P.sn_r[s_]), int(P.sn_c0[s_ + 1] - P.sn_c0[s_])
-        lev += [int(P.sn_level[s_])] * (1 if r_ <= 1024 else -(-(r_ - w_) // 256))
-    lev = np.array(lev)
-    assert len(lev) == nf
+    # level of the item at each forward position (a sliced front has several items): from the items themselves
+    item_dt = np.dtype([("spf", "<i8"), ("spb", "<i8"), ("uoff", "<i8"), ("rowoff", "<i8"), ("c0", "<i4"), ("w", "<i4"), ("r", "<i4"),
+                        ("nchild", "<i4"), ("Qf", "<i4"), ("Ef", "<i4"), ("Pb", "<i4"), ("Eb", "<i4"), ("c_uoff", "<i8", 4),
+                        ("c_invoff", "<i4", 4), ("Loff", "<i8"), ("xbegin", "<i4"), ("xend", "<i4"), ("a0", "<i4"), ("a1", "<i4"),
+                        ("sl", "<i4"), ("nsl", "<i4"), ("poff", "<i8")])
+    raw = np.empty(nf * item_dt.itemsize, dtype=np.uint8)
+    lib.hipfact_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    assert lib.hipfact_debug_copy(f._h, b"sitems", raw.ctypes.data_as(C.c_void_p), raw.nbytes) == 0
+    items = raw.view(item_dt)
+    front_of_c0 = {int(P.sn_c0[s_]): s_ for s_ in range(P.nsuper)}
+    lev = np.array([int(P.sn_level[front_of_c0[int(c)]]) for c in items["c0"]])
+    print(f"# {P.nsuper} fronts, {nf} items ({int((items['nsl'] > 1).sum())} of them row slices)")
     print("# fused solve launch, us since the first workgroup started.  per level: workgroups, entry (min..max), waited (max), posted (max)")
     for name, sl, levels in (("forward", slice(0, nf), lev), ("backward", slice(nf, 2 * nf), lev[::-1])):
         tt = t[sl]
