@@ -39,7 +39,8 @@ while time.time() - t0 < budget:
             "refine_steps": int(rng.choice([0, 1])), "use_graph": int(rng.choice([0, 1, 1])),
             "solve_fused": int(rng.choice([1, 1, 0])), "spanel_fold": int(rng.choice([1, 1, 0])),
             "spanel_fold_room": int(rng.choice([224, 16, 256])), "rhs_fused": int(rng.choice([1, 1, 0])),
-            "decide_lazy": int(rng.choice([1, 1, 0]))}
+            "decide_lazy": int(rng.choice([1, 1, 0])), "solve_slices": int(rng.choice([1, 1, 0])),
+            "chain_fuse": int(rng.choice([1, 1, 0])), "factor_top_levels": int(rng.choice([1 << 20, 1 << 20, 3]))}
     for k, v in opts.items():
         fact.set_option(k, v)
     try:
