@@ -27,11 +27,14 @@ spbytes = int(fact.info("solve_panel_bytes"))
 # item layout: 2 ll, 2 ll, 4 int, 4 int, 4 ll, 4 int, 1 ll  = 16+16+16+16+32+16+8 = 120 bytes
 item_dt = np.dtype([("spf", "<i8"), ("spb", "<i8"), ("uoff", "<i8"), ("rowoff", "<i8"), ("c0", "<i4"), ("w", "<i4"), ("r", "<i4"),
                     ("nchild", "<i4"), ("Qf", "<i4"), ("Ef", "<i4"), ("Pb", "<i4"), ("Eb", "<i4"), ("c_uoff", "<i8", 4),
-                    ("c_invoff", "<i4", 4), ("Loff", "<i8"), ("xbegin", "<i4"), ("xend", "<i4")])
+                    ("c_invoff", "<i4", 4), ("Loff", "<i8"), ("xbegin", "<i4"), ("xend", "<i4"), ("a0", "<i4"), ("a1", "<i4"),
+                    ("sl", "<i4"), ("nsl", "<i4"), ("poff", "<i8")])
 print("itemsize", item_dt.itemsize)
-items = dcopy("sitems", P.nsuper * item_dt.itemsize // 8).view(item_dt)
-SPf = dcopy("SPf", int(sum(((it["Ef"] * it["r"] * it["Qf"] + 1) & ~1) for it in items)))
-SPb = dcopy("SPb", int(sum(((it["Eb"] * it["w"] * it["Pb"] + 1) & ~1) for it in items)))
+items = dcopy("sitems", int(fact.info("solve_items")) * item_dt.itemsize // 8).view(item_dt)
+def rows_of(it):
+    return (int(it["w"]) if int(it["sl"]) == 0 else 0) + int(it["a1"]) - int(it["a0"])
+SPf = dcopy("SPf", int(sum(((int(it["Ef"]) * rows_of(it) * int(it["Qf"]) + 1) & ~1) for it in items)))
+SPb = dcopy("SPb", int(sum(((int(it["Eb"]) * int(it["w"]) * int(it["Pb"]) + 1) & ~1) for it in items)))
 worst = 0
 for it in items:
     w, r = int(it["w"]), int(it["r"])
@@ -39,19 +42,22 @@ for it in items:
     X = np.tril(panel[:w, :w], -1) + np.eye(w)
     d = np.diag(panel[:w, :w])
     S = np.vstack([X, -(panel[w:, :w] @ X)])
+    Sb = S.copy(); Sb[:w] /= d[:, None]
+    # the item's rows: the pivot rows (slice 0 only) and the update rows [a0, a1)
+    sel = (list(range(w)) if int(it["sl"]) == 0 else []) + [w + a for a in range(int(it["a0"]), int(it["a1"]))]
+    ro = len(sel)
     Q, E = int(it["Qf"]), int(it["Ef"])
-    TS = r * Q
-    got = np.zeros((r, w))
+    TS = ro * Q
+    got = np.zeros((ro, w))
     for k in range(w):
-        got[:, k] = SPf[it["spf"] + (k // Q) * TS + (k % Q) * r: it["spf"] + (k // Q) * TS + (k % Q) * r + r]
-    e1 = np.abs(got - S).max()
+        got[:, k] = SPf[it["spf"] + (k // Q) * TS + (k % Q) * ro: it["spf"] + (k // Q) * TS + (k % Q) * ro + ro]
+    e1 = np.abs(got - S[sel]).max()
     Pb, Eb = int(it["Pb"]), int(it["Eb"])
     TSb = w * Pb
-    gotb = np.zeros((r, w))
-    for i in range(r):
+    gotb = np.zeros((ro, w))
+    for i in range(ro):
         gotb[i, :] = SPb[it["spb"] + (i // Pb) * TSb + (i % Pb) * w: it["spb"] + (i // Pb) * TSb + (i % Pb) * w + w]
-    Sb = S.copy(); Sb[:w] /= d[:, None]
-    e2 = np.abs(gotb - Sb).max()
+    e2 = np.abs(gotb - Sb[sel]).max()
     worst = max(worst, e1, e2)
 print("panel max err", worst)
 b = np.random.default_rng(0).standard_normal(N)
