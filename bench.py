@@ -239,6 +239,36 @@ def load_traffic(kernel_name):
         "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernels sha %s" % pmc["_kernels_sha16"]
 
 
+def load_spmv_traffic():
+    """HBM bytes per launch of the three sparse products, from PMC passes that run ONE product each
+    (`bench.py --spmv-only NAME` under rocprofv3 --pmc; the products share a kernel template)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_spmv.json")))
+    except (OSError, ValueError):
+        return None, "no profiles/%s_pmc_spmv.json" % PROFILE_TAG
+    if pmc.get("_kernels_sha16") != kernels_sha():
+        return None, "profiles/%s_pmc_spmv.json was measured on other kernel sources" % PROFILE_TAG
+    return pmc, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, one pass per counter and product, kernels sha %s" % pmc["_kernels_sha16"]
+
+
+def spmv_setup(fact, J, n, m, dev, rngh):
+    import scipy.sparse as sp
+    import torch
+
+    from sleqp_amd.fact import SpMat
+    from sleqp_amd.sparse import SleqpMat
+
+    diags = [rngh.standard_normal(n - k) * 0.1 for k in range(1, 6)]
+    Hl = sp.diags([np.full(n, 2.0)] + diags, [0, -1, -2, -3, -4, -5], format="csc")
+    Hl.sort_indices()
+    Jd = SpMat(fact, SleqpMat.from_scipy(J))
+    Hd = SpMat(fact, SleqpMat(n, n, Hl.indptr, Hl.indices, Hl.data))
+    xs = torch.randn(max(n, m), dtype=torch.float64, device=dev)
+    ys = torch.empty(max(n, m), dtype=torch.float64, device=dev)
+    ops = (("J_x", Jd, 0, (m, n, J.nnz)), ("JT_y", Jd, 1, (n, m, J.nnz)), ("H_sym_x", Hd, 2, (n, n, 2 * Hl.nnz - n)))
+    return Hl, Jd, Hd, xs, ys, ops
+
+
 def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     """What an unmodified SLEQP sees: the SleqpFact vtable unit of SURVEY.md §8(d) through the C shim
     (shim/fact_hipfact.c): sleqp_fact_set_matrix(host K) + sleqp_fact_solve(sparse rhs) +
@@ -406,6 +436,7 @@ def main():
     ap.add_argument("--no-ceilings", action="store_true", help="skip the STREAM / DGEMM ceiling microbenchmarks")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / working-set / SQP-ratio measurements")
     ap.add_argument("--solves-per-factor", type=int, default=1)
+    ap.add_argument("--spmv-only", default=None, help="(profiling) run only this sparse product 20 times: J_x, JT_y or H_sym_x")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -428,6 +459,14 @@ def main():
     J, N, cp, ri, vx, b = make_problem(args.workload, seed=rep.problem_seed())
     n, m = J.shape[1], J.shape[0]
     fact = HipFact(device=local_rank, refine_steps=args.refine)
+    if args.spmv_only:
+        _, _, _, xs, ys, ops = spmv_setup(fact, J, n, m, dev, np.random.default_rng(7))
+        for name, M, trans, _ in ops:
+            if name == args.spmv_only:
+                for _ in range(20):
+                    M.mult_device(trans, xs.data_ptr(), ys.data_ptr())
+        fact.synchronize()
+        return
     t0 = time.perf_counter()
     fact.set_matrix(SleqpMat(N, N, cp, ri, vx))  # cold call: analysis + upload + first factorisation
     fact.synchronize()
@@ -522,16 +561,10 @@ def main():
         import scipy.sparse as sp
 
         rngh = np.random.default_rng(7)
-        diags = [rngh.standard_normal(n - k) * 0.1 for k in range(1, 6)]
-        Hl = sp.diags([np.full(n, 2.0)] + diags, [0, -1, -2, -3, -4, -5], format="csc")
-        Hl.sort_indices()
-        Jd = SpMat(fact, SleqpMat.from_scipy(J))
-        Hd = SpMat(fact, SleqpMat(n, n, Hl.indptr, Hl.indices, Hl.data))
-        xs = torch.randn(max(n, m), dtype=torch.float64, device=dev)
-        ys = torch.empty(max(n, m), dtype=torch.float64, device=dev)
+        Hl, Jd, Hd, xs, ys, ops = spmv_setup(fact, J, n, m, dev, rngh)
         spmv = {}
-        for name, M, trans, (r, c, nz) in (("J_x", Jd, 0, (m, n, J.nnz)), ("JT_y", Jd, 1, (n, m, J.nnz)),
-                                           ("H_sym_x", Hd, 2, (n, n, 2 * Hl.nnz - n))):
+        pmc_spmv, pmc_note = load_spmv_traffic()
+        for name, M, trans, (r, c, nz) in ops:
             for _ in range(5):
                 M.mult_device(trans, xs.data_ptr(), ys.data_ptr())
             fact.synchronize()
@@ -541,7 +574,14 @@ def main():
             fact.synchronize()
             dt = (time.perf_counter() - t0) / 200
             by = spmv_bytes(r, c, nz if trans != 2 else Hl.nnz)
-            spmv[name] = {"us": dt * 1e6, "algorithmic_GBps": by / dt / 1e9, "frac_of_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS}
+            spmv[name] = {"us": dt * 1e6, "algorithmic_GBps": by / dt / 1e9, "frac_of_hbm_peak": by / dt / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes": by}
+            if pmc_spmv and name in pmc_spmv:
+                # HBM bytes per launch from rocprofv3 --pmc (one pass per counter and product, scripts/refresh_profiles.sh)
+                tr = pmc_spmv[name]["fetch_bytes_per_launch_x2"] + pmc_spmv[name]["write_bytes_per_launch"]
+                spmv[name]["rocprof_hbm_bytes"] = tr
+                spmv[name]["rocprof_hbm_GBps"] = tr / dt / 1e9
+        spmv["rocprof_source"] = pmc_note
         extras["spmv"] = spmv
         # ---- device-resident Krylov loops, 20 iterations each
         grad = rngh.standard_normal(n)

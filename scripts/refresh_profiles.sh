@@ -13,9 +13,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python
 # HBM traffic: counters in passes of their own (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
+# the three sparse products share a kernel template: one pass per counter and product
+for OP in J_x JT_y H_sym_x; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_spmv_fetch_${OP}_$TAG -- python3 $REPO/bench.py --spmv-only $OP > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_spmv_write_${OP}_$TAG -- python3 $REPO/bench.py --spmv-only $OP > /dev/null 2>&1
+done
 cd $REPO
 python scripts/pmc_summary.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.txt 2>&1
 find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+python scripts/pmc_spmv_summary.py $OUT $TAG $OUT/${TAG}_pmc_spmv.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
+cp $OUT/${TAG}_pmc_spmv.json $REPO/profiles/${TAG}_pmc_spmv.json
 # the bench line below reads roofline.traffic from profiles/ (and checks the kernel sources' hash recorded in it)
 cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/${TAG}_pmc_traffic.json
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
