@@ -683,6 +683,18 @@ def main():
             "analysis_s": fact.info("analysis_s"),
             "scaled_residual": resid,
         }
+        # rocprof view of one solve (north_star: HBM GB/s on the triangular solves): bytes per launch of its kernels
+        # from the PMC passes (tree with both sweeps and the right-hand side, x update, residual), when they match
+        # the sources this run uses
+        if args.workload == "banded_n1e5_m5e4":
+            parts, note = [], None
+            for kname in ("k_solve_tree", "void k_x_saddle<false>", "k_residual_saddle"):
+                tr, note = load_traffic(kname)
+                parts.append(tr)
+            if all(v is not None for v in parts):
+                out["solve_only"]["rocprof_hbm_bytes"] = sum(parts)
+                out["solve_only"]["rocprof_hbm_GBps"] = sum(parts) / t_solve / 1e9
+                out["solve_only"]["rocprof_source"] = note
         out.update(extras)
         # dense-front workloads (config 3): the Schur kernel is bound by the fp64 matrix cores, not by HBM
         flops = fact.info("flops")
