@@ -1096,6 +1096,42 @@ def test_device_steihaug_vs_oracle(fact, radius):
     assert np.linalg.norm(step) <= radius * (1 + 1e-10)
 
 
+def test_krylov_loops_on_a_plan_with_sliced_fronts(fact):
+    """Dense Schur complement (tall fronts: row-sliced items in the fused solve launch, chain levels as small
+    dataflow launches) under the device-resident Krylov loops.  With H = c I the EQP step inside a large trust
+    region is -P g / c, P the projection onto the null space of the working-set rows: both loops must return it,
+    and the projection must be idempotent and feasible."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 3000, 1500
+    J = synth.uniform_jacobian(n, m, 10, 9)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.0, 1)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    assert fact.info("fused_solve") == 1 and fact.info("solve_items") > fact.info("nsuper")
+    g = np.random.default_rng(8).standard_normal(n)
+    pg = aug.project_nullspace(SleqpVec.from_raw(g)).to_raw()
+    ppg = aug.project_nullspace(SleqpVec.from_raw(pg)).to_raw()
+    assert rel_err(ppg, pg) <= 1e-9
+    assert np.abs(J @ pg).max() <= 1e-9 * np.abs(g).max() * abs(J).sum(axis=1).max()
+    c = 2.5
+    HL = sp.identity(n, format="csc") * c
+    H = SpMat(fact, SleqpMat.from_scipy(sp.csc_matrix(HL)))
+    for method in (0, 1):
+        # (the reference's interior test is absolute, |r.g| < (1e-2 stat_tol)^2: 1e-10 here, above the rounding
+        # level of r.g for |g| ~ 40 - at the default it is 1e-16 and only met by chance)
+        step, dual, its = fact.tr_solve(H, g, 1e6, method=method, stat_tol=1e-3)
+        assert rel_err(step, -pg / c) <= 1e-8 and its <= 3
+        assert np.abs(J @ step).max() <= 1e-9 * np.abs(g).max() * abs(J).sum(axis=1).max()
+    # trust region active: the step is the scaled projected gradient
+    radius = 0.25 * np.linalg.norm(pg) / c
+    for method in (0, 1):
+        step, dual, its = fact.tr_solve(H, g, radius, method=method, stat_tol=1e-3)
+        assert abs(np.linalg.norm(step) - radius) <= 1e-8 * radius
+        assert rel_err(step, -pg * radius / np.linalg.norm(pg)) <= 1e-7
+
+
 def test_device_steihaug_negative_curvature(fact):
     from sleqp_amd.fact import SpMat, StandardAugJac
     from sleqp_amd.sparse import SleqpMat
