@@ -326,6 +326,31 @@ def test_generic_mode_on_device(fact):
         assert scaled_residual(mat, z, b) <= 1e-12
 
 
+def test_generic_mode_with_tall_fronts(fact):
+    """General symmetric (SPD) input whose factor fills in densely: fronts of more than 1024 rows, i.e. row-sliced
+    items in the fused solve launch, reached through the non-saddle front end (gather / scatter by the permutation
+    instead of the saddle products)."""
+    from sleqp_amd.sparse import SleqpMat
+
+    A = synth.uniform_jacobian(2600, 2200, 8, 4)  # S = A A^T + I: the reduced matrix of a dense-Schur problem
+    M = (A @ A.T + sp.eye(2200)).tocsc()
+    L = sp.tril(M, format="csc")
+    L.sort_indices()
+    N = M.shape[0]
+    fact.set_matrix(SleqpMat(N, N, L.indptr, L.indices, L.data))
+    assert fact.info("saddle") == 0.0 and fact.info("max_r") > 1024
+    assert fact.info("fused_solve") == 1 and fact.info("solve_items") > fact.info("nsuper")
+    rng = np.random.default_rng(2)
+    dense = M.toarray()
+    for _ in range(3):
+        b = rng.standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert rel_err(z, np.linalg.solve(dense, b)) <= 1e-9
+        assert scaled_residual(M, z, b) <= 1e-12
+    assert fact.info("solve_timeouts") == 0
+
+
 def test_condition_estimate(fact):
     from sleqp_amd.sparse import SleqpMat
 
