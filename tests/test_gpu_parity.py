@@ -923,14 +923,19 @@ def test_non_finite_right_hand_side_does_not_stall_the_sweeps(fact):
     assert scaled_residual(K, good, b) <= 1e-9
 
 
-def test_dataflow_timeout_falls_back_to_per_level_launches(fact):
+@pytest.mark.parametrize("shape", ["banded", "dense_chain"])
+def test_dataflow_timeout_falls_back_to_per_level_launches(fact, shape):
     """The single-launch kernels assume in-order workgroup dispatch; their waits are bounded.  A timeout (injected
     here through the test hook) switches the handle to the per-level launches for good and repeats the work:
-    the caller sees a correct factorisation / solution, not an error."""
+    the caller sees a correct factorisation / solution, not an error.  (dense_chain: tall fronts, i.e. row-sliced
+    solve items and chain levels as small dataflow launches before the fallback.)"""
     from sleqp_amd.sparse import SleqpMat
 
-    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 17)
-    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    if shape == "banded":
+        J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 17)
+        N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    else:
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(synth.uniform_jacobian(3000, 1500, 10, 9))
     K = synth.kkt_full_matrix(N, kc, kr, kd)
     b = np.random.default_rng(5).standard_normal(N)
     fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
