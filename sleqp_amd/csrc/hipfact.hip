@@ -235,6 +235,7 @@ struct hipfact_handle : PlanState {
                                   // latency-bound top-of-tree launch slows down by as much as the overlap saves: 0.949 vs 0.940 ms)
   bool chain_fuse = true;         // single-front levels of a dense chain: pivot + panel items as one small dataflow launch
   bool solve_slices = true;       // fused solve: fronts whose panel share does not fit the registers of one item are row-sliced
+  bool speculate = true;          // set_matrix: queue values + factorisation before the pattern comparison has finished
   bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
@@ -1782,11 +1783,16 @@ static int ensure_plan(hipfact_handle* h, int N, const int* colptr, const int* r
 
 // factorisation + verdict; a timed-out dataflow launch is repeated once on the per-level path (fresh launches,
 // same process)
+static int check_factor(hipfact_handle* h, bool could_fall_back);
 static int factor_and_check(hipfact_handle* h) {
+  const bool could_fall_back = !h->no_dataflow;
   int rc = factor_async(h);
   if (rc) return rc;
-  const bool could_fall_back = !h->no_dataflow;
-  rc = check_info(h);
+  return check_factor(h, could_fall_back);
+}
+// the verdict on a queued factorisation (synchronises); a timed-out dataflow launch is repeated on the per-level path
+static int check_factor(hipfact_handle* h, bool could_fall_back) {
+  int rc = check_info(h);
   if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->info_host[INFO_TIMEOUT] != 0) {
     if ((rc = factor_async(h))) return rc;
     rc = check_info(h);
@@ -1903,7 +1909,24 @@ int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* r
     h->error = "hipfact_set_matrix: invalid arguments";
     return HIPFACT_EINVAL;
   }
-  if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) return rc;
+  // Steady state of an SQP run: the pattern is the active plan's.  All the host has to do then is compare 5 MB of
+  // indices - which it can do WHILE the device works: the values and the factorisation are queued first on the
+  // assumption that the pattern matches, and the comparison runs beside them.  If it does not match, what was
+  // queued is discarded (it ran on the old plan's own buffers) and the ordinary path follows.
+  const long long nnz_in = N > 0 ? colptr[N] : 0;
+  if (h->speculate && h->have_plan && !h->from_jacobian && h->plan.N == N && h->plan.nnzK == nnz_in &&
+      (size_t)nnz_in * sizeof(double) >= (64u << 10)) {
+    const int analyses = h->analyses, swaps = h->plan_swaps;
+    const bool could_fall_back = !h->no_dataflow;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpyAsync(h->d_Kval.p, vals, (size_t)nnz_in * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = factor_async(h))) return rc;
+    if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) return rc;
+    if (h->analyses == analyses && h->plan_swaps == swaps) return check_factor(h, could_fall_back);
+    HCHECK(h, hipStreamSynchronize(h->stream));  // another plan is active now: start over on it
+  } else if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) {
+    return rc;
+  }
   const size_t nnz = (size_t)h->plan.nnzK;
   if (nnz > 0) {
     HCHECK(h, hipStreamSynchronize(h->stream));  // a copy out of the staging buffer may still be in flight
@@ -1975,22 +1998,35 @@ int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices
       return HIPFACT_EINVAL;
     }
   HCHECK(h, hipMemsetAsync(h->d_rhs.p, 0, (size_t)N * sizeof(double), h->stream));
+  bool borrowed = false;
   if (nnz > 0) {
     const size_t bytes = (size_t)nnz * (sizeof(double) + sizeof(int));
-    HCHECK(h, hipStreamSynchronize(h->stream));
-    HCHECK(h, h->h_stage.ensure(bytes));
     HCHECK(h, h->d_sp_val.ensure((size_t)nnz * sizeof(double)));
     HCHECK(h, h->d_sp_idx.ensure((size_t)nnz * sizeof(int)));
-    double* sv = h->h_stage.as<double>();
-    int* si = reinterpret_cast<int*>(sv + nnz);
-    memcpy(sv, data, (size_t)nnz * sizeof(double));
-    memcpy(si, indices, (size_t)nnz * sizeof(int));
-    HCHECK(h, hipMemcpyAsync(h->d_sp_val.p, sv, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(h->d_sp_idx.p, si, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const void *pv = data, *pi = indices;
+    if (bytes >= (64u << 10)) {
+      // long vectors straight from the caller's arrays (the copy engine pins them in place, see hipfact_set_matrix);
+      // they are only borrowed for this call: the copies are awaited below, the solve is not
+      borrowed = true;
+    } else {
+      HCHECK(h, hipStreamSynchronize(h->stream));
+      HCHECK(h, h->h_stage.ensure(bytes));
+      double* sv = h->h_stage.as<double>();
+      int* si = reinterpret_cast<int*>(sv + nnz);
+      memcpy(sv, data, (size_t)nnz * sizeof(double));
+      memcpy(si, indices, (size_t)nnz * sizeof(int));
+      pv = sv;
+      pi = si;
+    }
+    HCHECK(h, hipMemcpyAsync(h->d_sp_val.p, pv, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->d_sp_idx.p, pi, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (borrowed) HCHECK(h, hipEventRecord(h->ev_fork, h->stream));
     hipLaunchKernelGGL(k_scatter_sparse, dim3(nblocks(nnz)), dim3(FB), 0, h->stream, nnz, h->d_sp_idx.as<int>(),
                        h->d_sp_val.as<double>(), h->d_rhs.as<double>());
   }
-  return solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
+  rc = solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
+  if (borrowed) HCHECK(h, hipEventSynchronize(h->ev_fork));
+  return rc;
 }
 
 int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol) {
@@ -2017,21 +2053,22 @@ int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
   if ((rc = finish_solve(h))) return rc;
   if (cnt == 0) return HIPFACT_OK;
   HCHECK(h, hipStreamSynchronize(h->stream));
-  HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
-  HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
-                           h->stream));
+  // long ranges straight into the caller's array (check_info below synchronises)
+  const bool direct = cnt * sizeof(double) >= (64u << 10);
+  if (!direct) HCHECK(h, h->h_stage.ensure(cnt * sizeof(double)));
+  void* dst = direct ? static_cast<void*>(out) : h->h_stage.p;
+  HCHECK(h, hipMemcpyAsync(dst, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   const bool could_fall_back = !h->no_dataflow;
   rc = check_info(h, "solve");  // synchronises
   if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->factored && h->last_b && h->last_z) {
     // the sweep timed out: the same solve once more through the per-level kernels
     if ((rc = solve_async(h, h->last_b, h->last_z))) return rc;
     if ((rc = finish_solve(h))) return rc;
-    HCHECK(h, hipMemcpyAsync(h->h_stage.p, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost,
-                             h->stream));
+    HCHECK(h, hipMemcpyAsync(dst, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     rc = check_info(h, "solve");
   }
   if (rc) return rc;
-  memcpy(out, h->h_stage.p, cnt * sizeof(double));
+  if (!direct) memcpy(out, h->h_stage.p, cnt * sizeof(double));
   return HIPFACT_OK;
 }
 
@@ -2939,6 +2976,10 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   if (!strcmp(name, "solve_slices")) {  // 0: one item per front in the fused solve launch (fronts of up to 1024 rows only)
     if (h->solve_slices != (value != 0.0)) invalidate_plans(h);
     h->solve_slices = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "speculate")) {
+    h->speculate = value != 0.0;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "chain_fuse")) {
