@@ -330,8 +330,8 @@ def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     out = {"rate": 1.0 / t_unit, "unit": "factor+solve/s", "ms_per_unit": t_unit * 1e3,
            "cold_first_call_s": t_cold, "solve_plus_solution_ms": t_solve * 1e3,
            "pcie_bytes_per_unit": {"up_set_matrix": 8 * nnz, "up_rhs": 12 * N, "down_solution": 8 * n},
-           "note": "through shim/fact_hipfact.c (the five SleqpFact callbacks): pattern compare on the host, "
-                   "values copied from the caller's array by the copy engine, zero-pivot check (D2H + sync), sparse rhs upload + scatter, "
+           "note": "through shim/fact_hipfact.c (the five SleqpFact callbacks): pattern compare on the host (beside the factorisation, which is queued first), "
+                   "values, rhs and solution copied from / to the caller's arrays by the copy engine, zero-pivot check (D2H + sync), sparse rhs upload + scatter, "
                    "solve, refinement verdict, solution(0, n) D2H and sleqp_vec_set_from_raw on the host"}
     shim.sleqp_vec_free(C.byref(rhs))
     shim.sleqp_vec_free(C.byref(sol))
