@@ -127,6 +127,11 @@ struct RawSuper {
   std::vector<int> rows;  // sorted, own columns first
   int64_t zeros = 0;
   bool dead = false;
+  // columns (relative to c0) at which another subtree joins the chain: the column has further
+  // children besides its predecessor.  The structure nests, so the columns form one front, but a
+  // front that has to be cut at the width cap is cut THERE: children hang off the part their first
+  // update row lies in, and an even cut would push them (and their whole subtree) one level down.
+  std::vector<int> joins;
 };
 
 // Supernodal symbolic factorisation for a postordered matrix.  Fills the
@@ -169,6 +174,7 @@ void symbolic(const Graph& g, const std::vector<int>& perm, const std::vector<in
     }
     if (chain && extras.empty()) {
       RawSuper& s = sn.back();
+      if (next[head[j]] != -1) s.joins.push_back(j - s.c0);  // more children than the chain predecessor
       s.w += 1;
       sn_of[j] = (int)sn.size() - 1;
       colcount[j] = (int)s.rows.size() - (j - s.c0);
@@ -196,7 +202,14 @@ void symbolic(const Graph& g, const std::vector<int>& perm, const std::vector<in
 
 inline int64_t trapezoid(int64_t w, int64_t r) { return w * r - w * (w - 1) / 2; }
 
-void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
+// front that holds column c now (fronts merged into their successor are dead: follow the chain)
+inline int col2sn_live(const std::vector<RawSuper>& sn, const std::vector<int>& col2sn, int c) {
+  int s = col2sn[c];
+  while (s >= 0 && sn[s].dead) ++s;  // a dead front was merged into the next one (adjacent merges only at that point)
+  return s;
+}
+
+void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm, std::vector<int>& perm, std::vector<int>& iperm) {
   const int ns = (int)sn.size();
   if (ns == 0) return;
   std::vector<int> col2sn(m);
@@ -236,12 +249,90 @@ void amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm) {
     for (int k = 0; k < a.w; ++k) rows.push_back(a.c0 + k);
     rows.insert(rows.end(), b.rows.begin(), b.rows.end());
     b.rows.swap(rows);
+    {
+      std::vector<int> joins(a.joins);
+      joins.push_back(a.w);
+      for (int q : b.joins) joins.push_back(a.w + q);
+      b.joins.swap(joins);
+    }
     b.c0 = a.c0;
     b.w = wm;
     b.zeros = zeros;
     nch[p] += nch[s] - 1;
     a.dead = true;
     std::vector<int>().swap(a.rows);
+  }
+  // ---- adoption of childless fronts.  Only the LAST child of a front is adjacent to it in the
+  // postorder; the other children stay fronts of their own above, however small - typically the first
+  // few vertices a minimum-degree ordering removes from a nearly dense leaf subgraph (one column each,
+  // a slightly smaller structure than the clique behind them).  Each of them costs a whole tree level
+  // of dependent latency on the device for a handful of explicit zeros.  A childless front may be
+  // moved anywhere in front of its parent (any topological order of the elimination tree gives the
+  // same fill), so it is renumbered to sit right in front of the parent's columns and merged under
+  // the same zero-fraction rule.  Its columns occur in no other front's row list, and all other
+  // indices move by a monotone map: the row lists stay sorted.
+  std::vector<std::vector<int>> adopted(ns);
+  bool any_adopted = false;
+  if (prm.adopt_leaves) {
+    for (int s = 0; s < ns; ++s) {
+      RawSuper& a = sn[s];
+      if (a.dead || nch[s] != 0 || (int)a.rows.size() == a.w) continue;
+      const int p = col2sn_live(sn, col2sn, a.rows[a.w]);
+      if (p == s + 1 || p < 0) continue;
+      RawSuper& b = sn[p];
+      const int wm = a.w + b.w;
+      if (wm > prm.wmax) continue;
+      const int64_t ua = (int64_t)a.rows.size() - a.w;
+      const int64_t rb = (int64_t)b.rows.size();
+      const int64_t zeros = a.zeros + b.zeros + (int64_t)a.w * (rb - ua);
+      const int64_t tot = trapezoid(wm, a.w + rb);
+      const double frac = (double)zeros / (double)tot;
+      const bool ok = wm <= 4 || frac < (wm <= 32 ? prm.relax_small : wm <= 64 ? prm.relax_mid : prm.relax_big);
+      if (!ok) continue;
+      // b keeps its own numbering for now: rows = [adopted columns | own rows] is formed by the renumbering below
+      adopted[p].push_back(s);
+      std::vector<int> rows;
+      rows.reserve(a.w + b.rows.size());
+      rows.insert(rows.end(), a.rows.begin(), a.rows.begin() + a.w);  // (old numbers, own adoptions first; sorted once renumbered)
+      rows.insert(rows.end(), b.rows.begin(), b.rows.end());
+      b.rows.swap(rows);
+      for (int& q : b.joins) q += a.w;
+      b.joins.insert(b.joins.begin(), a.w);
+      b.w = wm;
+      b.zeros = zeros;
+      --nch[p];
+      a.dead = true;
+      std::vector<int>().swap(a.rows);
+      any_adopted = true;
+    }
+  }
+  if (any_adopted) {
+    // new numbers: fronts in order, the adopted columns of a front right in front of its own
+    std::vector<int> newidx(m, -1);
+    int next = 0;
+    for (int s = 0; s < ns; ++s) {
+      if (sn[s].dead) continue;
+      RawSuper& b = sn[s];
+      const int w = b.w;
+      for (int k = 0; k < w; ++k) newidx[b.rows[k]] = next++;  // first w rows = adopted columns, then own columns
+    }
+    assert(next == m);
+    for (int s = 0; s < ns; ++s) {
+      if (sn[s].dead) continue;
+      RawSuper& b = sn[s];
+      for (int& r : b.rows) r = newidx[r];
+      b.c0 = b.rows[0];
+      if (!std::is_sorted(b.rows.begin(), b.rows.end())) {
+        fprintf(stderr, "unsorted s %d w %d adopted %zu rows:", s, b.w, adopted[s].size());
+        for (size_t t = 0; t < b.rows.size(); ++t) if (t == 0 || b.rows[t] != b.rows[t-1] + 1 || t + 1 == b.rows.size()) fprintf(stderr, " [%zu]=%d", t, b.rows[t]);
+        fprintf(stderr, "\n");
+        abort();
+      }
+    }
+    std::vector<int> perm2(m);
+    for (int k = 0; k < m; ++k) perm2[newidx[k]] = perm[k];
+    perm.swap(perm2);
+    for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
   }
   std::vector<RawSuper> out;
   out.reserve(ns);
@@ -258,16 +349,41 @@ void split_wide(std::vector<RawSuper>& sn, int wmax) {
       out.push_back(std::move(s));
       continue;
     }
-    const int np = (s.w + wmax - 1) / wmax;
-    int done = 0;
-    for (int p = 0; p < np; ++p) {
-      const int wp = (s.w - done) / (np - p);
+    // segments between the joins, combined greedily up to the cap; a segment wider than the cap
+    // (a genuine chain, e.g. a dense Schur complement) is cut evenly
+    std::vector<int> cuts;  // first columns of the parts
+    {
+      std::vector<int> bounds(1, 0);
+      for (int q : s.joins)
+        if (q > bounds.back() && q < s.w) bounds.push_back(q);
+      bounds.push_back(s.w);
+      int start = 0;
+      cuts.push_back(0);
+      for (size_t t = 1; t < bounds.size(); ++t) {
+        const int seg0 = bounds[t - 1], seg1 = bounds[t];
+        if (seg1 - start <= wmax) continue;  // the segment still fits the open part
+        if (seg0 > start) {                  // close the open part in front of the segment
+          cuts.push_back(seg0);
+          start = seg0;
+        }
+        if (seg1 - start > wmax) {  // the segment alone is too wide: even pieces
+          const int len = seg1 - start, np = (len + wmax - 1) / wmax;
+          int done = 0;
+          for (int p = 0; p + 1 < np; ++p) {
+            done += (len - done) / (np - p);
+            cuts.push_back(start + done);
+          }
+          start = cuts.back();
+        }
+      }
+    }
+    cuts.push_back(s.w);
+    for (size_t p = 0; p + 1 < cuts.size(); ++p) {
       RawSuper t;
-      t.c0 = s.c0 + done;
-      t.w = wp;
-      t.rows.assign(s.rows.begin() + done, s.rows.end());
+      t.c0 = s.c0 + cuts[p];
+      t.w = cuts[p + 1] - cuts[p];
+      t.rows.assign(s.rows.begin() + cuts[p], s.rows.end());
       out.push_back(std::move(t));
-      done += wp;
     }
   }
   sn.swap(out);
@@ -291,6 +407,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   if (const char* e = getenv("HIPFACT_ND_LEAF")) prm.nd_leaf = atoi(e);
   if (const char* e = getenv("HIPFACT_WMAX")) prm.wmax = atoi(e);
   if (const char* e = getenv("HIPFACT_MAX_CHILDREN")) prm.max_children = atoi(e);
+  if (const char* e = getenv("HIPFACT_ADOPT")) prm.adopt_leaves = atoi(e) != 0;
   if (const char* e = getenv("HIPFACT_ND_SEP_FRAC")) prm.nd_sep_frac = atof(e);
   if (const char* e = getenv("HIPFACT_RELAX")) {
     double a, b, c;
@@ -447,8 +564,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     if (prm.nd_leaf > 0)
       nd.leaf_size = prm.nd_leaf;
     else
-      nd.leaf_size = 256;
+      nd.leaf_size = std::max(prm.wmax, 32);  // a leaf subgraph that fits one front is not dissected further
+    if (const char* e = getenv("HIPFACT_ND_SMALL_SEP_FRAC")) nd.small_sep_frac = atof(e);
     if (const char* e = getenv("HIPFACT_ND_REFINE")) nd.refine = atoi(e) != 0;
+    if (const char* e = getenv("HIPFACT_ND_BALANCE")) nd.balance = atof(e);
     nd_order(g, nd, perm);
   }
   std::vector<int> iperm(m);
@@ -482,7 +601,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     P.flops += (double)colcount[k] * colcount[k];
   }
   tick("etree + symbolic (2 passes)");
-  amalgamate(sn, m, prm);
+  amalgamate(sn, m, prm, perm, iperm);
   split_wide(sn, prm.wmax);
 
   // ---- final supernode arrays

@@ -22,7 +22,12 @@ void amd_order(const Graph& g, std::vector<int>& perm);
 struct NDParams {
   int leaf_size = 200;        // stop dissecting below this many vertices
   double max_sep_frac = 0.20; // reject separators larger than this fraction of the subgraph
-  double balance = 0.30;      // smaller side must hold at least this fraction
+  // ... except in small subgraphs (<= small_k vertices): there the device cost is the NUMBER of tree
+  // levels (dependent latency), not the fill - a leaf subgraph wider than one front becomes a chain of
+  // fronts, one level each, where one more dissection gives two single-front leaves under one separator
+  double small_sep_frac = 0.45;
+  int small_k = 2048;
+  double balance = 0.15;      // smaller side must hold at least this fraction
   // FM-refined edge bisection + minimum vertex cover as a second separator candidate.  Off by
   // default: on the band-like benchmark graphs it shrinks the separators by ~3 % but the resulting
   // trees factor 1-5 % slower (HIPFACT_ND_REFINE=1 to try it on other graph classes).

@@ -275,6 +275,7 @@ struct NDState {
   std::mutex leaves_mutex;
   std::atomic<int> threads_running{1};
   int max_threads = 1;
+  const bool nd_debug = getenv("HIPFACT_ND_DEBUG") != nullptr;
 
   void leaf(const std::vector<int>& verts, int off) {
     int id;
@@ -597,7 +598,7 @@ struct NDState {
     return small >= prm.balance * k;
   }
 
-  void rec(std::vector<int> verts, int off) {
+  void rec(std::vector<int> verts, int off, int depth = 0) {
     const int k = (int)verts.size();
     if (k <= prm.leaf_size) {
       leaf(verts, off);
@@ -635,7 +636,7 @@ struct NDState {
         int o = off;
         for (auto& c : comps) {
           const int kc = (int)c.size();
-          rec(std::move(c), o);
+          rec(std::move(c), o, depth);
           o += kc;
         }
         return true;
@@ -741,23 +742,24 @@ struct NDState {
         sep.swap(s2);
       }
     }
-    if (sep.empty() || left.empty() || right.empty() || (double)sep.size() > prm.max_sep_frac * k) {
+    if (sep.empty() || left.empty() || right.empty() || (double)sep.size() > (k <= prm.small_k ? std::max(prm.max_sep_frac, prm.small_sep_frac) : prm.max_sep_frac) * k) {
       leaf(verts, off);
       return;
     }
     std::vector<int>().swap(verts);
     std::vector<int>().swap(order);
     const int nl = (int)left.size(), nr = (int)right.size();
+    if (nd_debug) fprintf(stderr, "nd depth %d k %d sep %zu left %d right %d nlev %d\n", depth, k, sep.size(), nl, nr, nlev);
     for (size_t t = 0; t < sep.size(); ++t) perm[off + nl + nr + t] = sep[t];
     if (std::min(nl, nr) >= 2048 && threads_running.load() < max_threads) {
       ++threads_running;
-      std::thread other([this, &left, off] { rec(std::move(left), off); });
-      rec(std::move(right), off + nl);
+      std::thread other([this, &left, off, depth] { rec(std::move(left), off, depth + 1); });
+      rec(std::move(right), off + nl, depth + 1);
       other.join();
       --threads_running;
     } else {
-      rec(std::move(left), off);
-      rec(std::move(right), off + nl);
+      rec(std::move(left), off, depth + 1);
+      rec(std::move(right), off + nl, depth + 1);
     }
   }
 };

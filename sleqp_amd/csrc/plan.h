@@ -34,6 +34,7 @@ struct PlanParams {
   double relax_mid = 0.4;     // ... <= 64
   double relax_big = 0.3;     // ... wider
   int max_children = 4;       // merges must not create fronts with more children (0 = unlimited); = MAXCH of the device
+  bool adopt_leaves = true;   // childless fronts that are not adjacent to their parent are renumbered and merged into it
   bool force_generic = false;
 };
 
