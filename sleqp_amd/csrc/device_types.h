@@ -58,7 +58,8 @@ struct TopFItem {
   int wait_id[MAXCH];   // children
   int wait_cnt[MAXCH];  // Schur workgroups of each child in this launch (0: finished before the launch)
   int target;           // Schur: panel workgroups of the own front
-  int crows;            // panel: rows per workgroup (128, or 64 with two waves per 16-row strip)
+  int crows;            // Schur: 64 = one 32 x 32 tile per workgroup (narrow levels), 128 = two teams with a 64 x 64 tile each
+  int prows;            // panel: rows per workgroup (128, or 64 with two waves per 16-row strip)
   int sidx, scount;     // Schur: index among / number of the Schur workgroups of the front
   int post;             // the pivot workgroup posts inv(L11) tile by tile, the panel workgroups poll for it (no flag hop)
   long long xoff;       // the front's wp x wp slot in the arena of posted pivot blocks

@@ -726,6 +726,17 @@ static int upload_plan(hipfact_handle* h) {
         const long long u = sn[s].r - sn[s].w, nt = (u + 31) / 32;
         return nt * (nt + 1) / 2;
       };
+      // panel rows per workgroup.  Levels that post the pivot block solve their panels by block substitution, one
+      // wave per strip of 16 rows and ONE computing wave per SIMD (64 rows per workgroup, the other four waves only
+      // poll and stage): the substitution is bound by the fp64 matrix pipe, and with two computing waves per SIMD a
+      // workgroup falls behind the pivot workgroup it follows
+      auto panel_rows = [&](int count) {
+#ifdef HIPFACT_PIVOT_V1
+        return count <= h->factor_top_fine ? 64 : 128;
+#else
+        return (count <= h->factor_top_post || count <= h->factor_top_fine) ? 64 : 128;
+#endif
+      };
       std::vector<TopFItem> tf;
       std::vector<size_t> level_end, panel_end;  // end of the items / of the pivot and panel items of each level in tf
       size_t lds = 0;
@@ -782,8 +793,9 @@ static int upload_plan(hipfact_handle* h) {
           }
           t.crows = fine ? 64 : 128;
           t.post = li.count <= h->factor_top_post;
+          t.prows = panel_rows(li.count);
           t.xoff = xoff[s];
-          t.target = (sn[s].r - sn[s].w + t.crows - 1) / t.crows;
+          t.target = (sn[s].r - sn[s].w + t.prows - 1) / t.prows;
           return t;
         };
         // Workgroups are dispatched in index order and a waiting one keeps its CU.  Pivot items:
@@ -802,7 +814,7 @@ static int upload_plan(hipfact_handle* h) {
         }
         for (int s : narrow_first) {
           const int u = sn[s].r - sn[s].w;
-          const int crows = fine ? 64 : 128;
+          const int crows = panel_rows(li.count);
           for (int b = 0; b < (u + crows - 1) / crows; ++b) tf.push_back(base(s, 1, b));
         }
         panel_end.push_back(tf.size());
@@ -845,7 +857,7 @@ static int upload_plan(hipfact_handle* h) {
           t.front = s;
           t.part2 = -1;
           if (P.sn_level[s] >= lvl) {
-            const int crows = h->levels[P.sn_level[s]].count <= h->factor_top_fine ? 64 : 128;
+            const int crows = panel_rows(h->levels[P.sn_level[s]].count);
             t.nwait = 1;
             t.target = (sn[s].r - sn[s].w + crows - 1) / crows;
           }
@@ -901,14 +913,15 @@ static int upload_plan(hipfact_handle* h) {
           t.nwait = t.it.nchild;  // the children finished in earlier launches: nothing to wait for
           for (int k = 0; k < t.nwait; ++k) t.wait_id[k] = P.child_idx[sn[s].child_begin + k];
           t.crows = 64;
+          t.prows = panel_rows(1);
           t.post = 1;
           t.xoff = xoff[s];
-          t.target = (sn[s].r - sn[s].w + 63) / 64;
+          t.target = (sn[s].r - sn[s].w + t.prows - 1) / t.prows;
           return t;
         };
         lm.mini_off = (long long)tf.size();
         tf.push_back(mini(0, 0));
-        for (int b = 0; b < (sn[s].r - sn[s].w + 63) / 64; ++b) tf.push_back(mini(1, b));
+        for (int b = 0; b < (sn[s].r - sn[s].w + panel_rows(1) - 1) / panel_rows(1); ++b) tf.push_back(mini(1, b));
         lm.mini_cnt = (int)(tf.size() - (size_t)lm.mini_off);
         lm.mini_lds = std::max(lm.lds_pivot, lm.lds_panel);
       }
@@ -3132,3 +3145,16 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
 }
 
 }  // extern "C"
+
+#ifdef HIPFACT_TRACE
+// in-kernel timeline of the dataflow launch (scripts/timeline.py; never part of the product build)
+extern "C" int hipfact_debug_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * hipfact::TRACE_WGS * 8);
+}
+extern "C" int hipfact_debug_trace_owner(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_own), sizeof(long long) * hipfact::TRACE_WGS * 8);
+}
+extern "C" int hipfact_debug_trace_pivot(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_piv), sizeof(long long) * hipfact::TRACE_WGS * 24);
+}
+#endif

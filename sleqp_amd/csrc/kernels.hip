@@ -169,6 +169,30 @@ __global__ __launch_bounds__(FB) void k_gather(long long n, const int* __restric
 // by the 16-column panel Y.  Phase D: region = two 64 x KC operand strips.
 // ---------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
+// In-kernel timeline (scripts/timeline.py builds a copy of the library with -DHIPFACT_TRACE): wall_clock64 stamps
+// of every workgroup of the dataflow launch (start, dependency met, work done, published) and of the chain wave
+// of its pivot role.  Compiled out of the product.
+#ifdef HIPFACT_TRACE
+constexpr int TRACE_WGS = 8192;
+__device__ long long g_trace[TRACE_WGS * 8];
+__device__ long long g_piv[TRACE_WGS * 24];
+__device__ long long g_own[TRACE_WGS * 8];  // row I of the pivot block handed to the chain wave (its owner's last update)
+#define TRW(slot)                                                                                  \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_trace[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#define TRP(slot)                                                                                \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_piv[blockIdx.x * 24 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define TRW(slot) \
+  do {            \
+  } while (0)
+#define TRP(slot) \
+  do {            \
+  } while (0)
+#endif
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // 1/d to ~1 ulp without the IEEE division sequence.  v_rcp_f64 is good to 2^-24.4 on gfx950
@@ -463,7 +487,9 @@ __device__ __forceinline__ double diag_step(double (&a)[16], double (&x)[4], dou
 }
 #endif
 
-__device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info) {
+// xout: the inverse as the lane holds it, X[li][4 cc + lk] - the A operand layout of the matrix cores (V2 chain)
+__device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratch, int k0, int* __restrict__ info,
+                                               double* xout = nullptr) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int lda = c.lda;
@@ -510,6 +536,10 @@ __device__ __forceinline__ void dev_diag_block(const FrontCtx& c, double* scratc
   nl = diag_step<14>(a, x, dsel, li, nl);
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) A[(k0 + li) + (k0 + 4 * cc + lk) * lda] = x[cc];
+  if (xout) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) xout[cc] = x[cc];
+  }
   const bool owner = (lk == 0);
   const bool bad = owner && ((dsel == 0.0) || !(fabs(dsel) <= 1.7e308));  // exactly singular or non-finite
   const bool neg = owner && !bad && (dsel < 0.0);
@@ -715,7 +745,37 @@ __device__ __forceinline__ ChildWait no_wait() {
 
 // ROWINV (8 waves): the inverse of the unit lower factor is formed block row by block row in
 // the shadow of the diagonal-block chain instead of by recursive doubling afterwards.
-template <bool ROWINV, bool CHAIN = false>
+// ---- LDS flags between the waves of one workgroup (free-running pivot block, V2 below): a wave publishes
+// "my tiles are written" with a release + store, a consumer spins on the word.  All lanes execute the same
+// scalar-uniform access.  Bounded spins: a hang would take the GPU with it.
+// (The data AND the flags live in LDS, whose operations complete in issue order per wave: waiting for the LDS
+// counter is all a release needs.  A workgroup-scope fence would also drain the wave's global stores - the tiles it
+// has just posted to the panel workgroups, 0.6 us per step of the chain.)
+__device__ __forceinline__ void lds_flag_set(int* f, int v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_add(int* f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_wait_ge(int* f, int v, int* __restrict__ info) {
+  int spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) {
+      if ((threadIdx.x & 63) == 0) atomicAdd(&info[INFO_TIMEOUT], 1);
+      break;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// LDS words of the free-running pivot block (behind the 1 / d array at Yp)
+enum { PF_DIAG = 0, PF_STAGE2 = 1, PF_LRDY = 2, PF_UPD = 10, PF_WORDS = 18 };
+
+__device__ __forceinline__ void dev_pivot_chain(const FrontCtx& c, double* dinv, int* flags, int* __restrict__ info);
+
+template <bool ROWINV, bool CHAIN = false, bool V2 = false>
 __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restrict__ info, int phases, const PullCtx& pc,
                                                 const ChildWait& cw, const PullMore pm = no_more()) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -725,7 +785,11 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   double* A = c.A;
   double* dd = c.dd;
   double* Yp = c.Yp;
-  double* scratch = Yp + 16 * lda;  // 32 doubles: the reciprocal pivots of the current diagonal block
+  // 32 doubles: the reciprocal pivots of the current diagonal block.  V2 keeps 1 / d of EVERY pivot (the waves
+  // run apart): the first wp doubles of the Y panel, which V2 does not use, followed by its flag words
+  double* scratch = V2 ? Yp : Yp + 16 * lda;
+  int* pflags = reinterpret_cast<int*>(Yp + wp);
+  if (V2 && tid < PF_WORDS) pflags[tid] = 0;  // (a barrier follows in every branch below before anybody signals)
   const double* __restrict__ P = c.P;
   if (pc.n > 0) {
     // pull-mode extend-add (8 waves, wp <= 128).  Order of issue = order of the dependent round
@@ -734,7 +798,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
     // 4 entries each) is completed first, so that wave 0 can factor the first diagonal block
     // while waves 1..7 finish the other columns (2 x 16 entries per thread).  Children are added
     // in child order on top of the original entry, as dev_assemble does.
-    int* invb = reinterpret_cast<int*>(scratch + 32);
+    int* invb = reinterpret_cast<int*>(Yp + 16 * lda + 32);
     int iv[MAXCH];
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) iv[ch] = (ch < pc.n && tid < w) ? pc.inv[ch][tid] : -1;
@@ -768,7 +832,9 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
       int o1[MAXCH][4], o2[2][2][8];
       pivot_offsets_stage1(pc, invb, wp, i1, kq1, o1);
       if (wave >= 1) pivot_offsets_stage2(pc, invb, wp, lane, wave, o2);
+      TRW(5);
       cw.wait();  // top-of-tree launch: everything above was requested before the children are awaited
+      TRW(1);
       double g1[MAXCH][4], g2[2][2][8];
 #pragma unroll
       for (int ch = 0; ch < MAXCH; ++ch)
@@ -797,8 +863,10 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
         for (int q = 0; q < 4; ++q) A[i1 + (kq1 + 4 * q) * lda] = v1[q];
       }
       __syncthreads();
+      TRP(0);
       if (wave == 0) {
         if (!(phases & 32)) dev_diag_block(c, scratch, 0, info);
+        TRP(1);
       } else {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
@@ -817,7 +885,7 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
             if (stage2_elem(wp, wave, lane, s2, j, i, k)) A[i + k * lda] = v[s2][j];
           }
       }
-      __syncthreads();
+      if (!V2) __syncthreads();  // V2: the chain wave goes on; the others signal PF_STAGE2 below
     } else {
       cw.wait();
       pivot_gather_stage1(pc, invb, wp, i1, kq1, v1);
@@ -880,7 +948,13 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   // reads block row kb of L any more.
   d4_t xpend = {0.0, 0.0, 0.0, 0.0};
   int xrow = -1, xcol = -1;
-  for (int kb = 0; kb < nbk; ++kb) {
+  if constexpr (V2) {
+    if (wave >= 1) lds_flag_add(&pflags[PF_STAGE2]);  // this wave's share of the block is in LDS
+    dev_pivot_chain(c, scratch, pflags, info);
+    TRW(4);
+    __syncthreads();
+  }
+  for (int kb = 0; kb < (V2 ? 0 : nbk); ++kb) {
     const int k0 = kb << 4;
     if (ROWINV && xrow >= 0) {
 #pragma unroll
@@ -1069,6 +1143,155 @@ __device__ __forceinline__ void dev_pivot_block(const FrontCtx& c, int* __restri
   }
 }
 
+
+// ---- V2 of the blocked LDL^T of the pivot block: free-running waves instead of two workgroup barriers per
+// block column.  The dependent chain of a front is diag(kb) -> block (kb+1, kb) of L -> update of the diagonal
+// tile (kb+1, kb+1) -> diag(kb+1); with barriers the chain wave also waited for everybody else's share of every
+// step (2.4 - 2.6 us per block column, of which the chain itself needs ~1.5).  Here
+//   wave 0 owns the chain: after diag(kb) it forms block (kb+1, kb) of L itself - transposed, Y^T = X_kk A^T, so
+//          that the accumulator registers are at once the A operand (L) and the B operand (Y) of the update of
+//          the diagonal tile, which never travels through LDS in between -, then diag(kb+1);
+//   wave I (1..7) owns block row I of the trailing matrix for good: in step kb < I-1 it forms L(I, kb) and
+//          updates its tiles (I, kb+1 .. I); nobody else ever writes that row, so no barrier is needed, only
+//          "tile (J, kb) of L is there" (PF_LRDY) for the B operands of the other rows J < I (= D L_J^T, formed
+//          from the L tile: tiles of L are written once and never overwritten, a Y panel would be reused);
+//   row kb+1 is handed to wave 0 once its owner has applied the steps < kb (PF_UPD).
+// Leaves L (unit lower, off-diagonal tiles), inv(L_kk) in the diagonal tiles, the pivots in dd and 1 / d in
+// dinv; the caller inverts L afterwards (recursive doubling, off the critical path: the panel workgroups of
+// the dataflow launch follow the POSTED tiles of L and solve by block substitution, dev_panel_rows_subst).
+// Needs 8 waves (one per block row, wp <= 128).
+__device__ __forceinline__ void dev_pivot_post_diag(const FrontCtx& c, int k0) {
+  if (!c.Xa) return;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int row = k0 + li;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = c.A[row + (k0 + lk + 4 * q) * c.lda];  // (one batch of LDS reads, then the stores)
+  const double dv = c.dd[row];
+  if (row >= c.w) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = k0 + lk + 4 * q;
+    if (col < row) post_f64(c.Xa + row + col * c.wp, v[q]);
+  }
+  if (lk == 0) post_f64(c.Xa + row + row * c.wp, dv);
+}
+
+__device__ __forceinline__ void dev_pivot_chain(const FrontCtx& c, double* dinv, int* flags, int* __restrict__ info) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, wp = c.wp, nbk = c.nbk, lda = c.lda;
+  double* A = c.A;
+  if (wave == 0) {
+    // (the inverse of the diagonal block stays in the registers: it is the A operand of the next block of L)
+    double x[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) x[cc] = A[li + (4 * cc + lk) * lda];
+    lds_flag_set(&flags[PF_DIAG], 1);
+    for (int kb = 0; kb + 1 < nbk; ++kb) {
+      const int k0 = kb << 4, r0 = k0 + 16;
+      if (kb == 0)
+        lds_flag_wait_ge(&flags[PF_STAGE2], 7, info);
+      else
+        lds_flag_wait_ge(&flags[PF_UPD + kb + 1], kb, info);
+      TRP(2 + 3 * kb);
+      // Y^T = X_kk A(kb+1, kb)^T: y[q] = Y[li][lk + 4 q]; the diagonal tile it updates is requested with the operands
+      double bv[4], di[4];
+      d4_t t;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[s] = A[(r0 + li) + (k0 + 4 * s + lk) * lda];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        di[q] = dinv[k0 + lk + 4 * q];
+        t[q] = A[(r0 + lk + 4 * q) + (r0 + li) * lda];
+      }
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y = MFMA_F64(x[s], bv[s], y);
+      d4_t l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        l[q] = y[q] * di[q];
+        A[(r0 + li) + (k0 + lk + 4 * q) * lda] = l[q];
+      }
+      lds_flag_set(&flags[PF_LRDY + kb + 1], kb + 1);
+      // diagonal tile (kb+1, kb+1) -= L Y^T, operands straight from the registers (k runs as lk + 4 s on both)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t = MFMA_F64(l[s], -y[s], t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A[(r0 + lk + 4 * q) + (r0 + li) * lda] = t[q];
+      if (c.Xa && r0 + li < w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) post_f64(c.Xa + (r0 + li) + (k0 + lk + 4 * q) * wp, l[q]);
+      }
+      TRP(3 + 3 * kb);
+      dev_diag_block(c, dinv + r0, r0, info, x);
+      TRP(4 + 3 * kb);
+      lds_flag_set(&flags[PF_DIAG], kb + 2);
+    }
+  } else if (wave != 4 && (wave < 4 ? wave + 1 : wave) < nbk) {
+    // rows 2 .. 7 on the waves 1, 2, 3, 5, 6, 7 (row 1 goes straight to the chain wave).  Wave 4 shares the SIMD of
+    // the chain wave - its matrix instructions would stretch the chain, and the chain's steady issue starves it until
+    // its row is the one the chain waits for - and posts the diagonal tiles instead.
+    const int I = wave < 4 ? wave + 1 : wave, i0 = I << 4;
+    for (int kb = 0; kb + 1 < I; ++kb) {
+      const int k0 = kb << 4;
+      lds_flag_wait_ge(&flags[PF_DIAG], kb + 1, info);
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double av = A[(k0 + li) + (k0 + 4 * s + lk) * lda];
+        const double bv = A[(i0 + li) + (k0 + 4 * s + lk) * lda];
+        y = MFMA_F64(av, bv, y);
+      }
+      d4_t l;
+      double dk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        l[q] = y[q] * dinv[k0 + lk + 4 * q];
+        dk[q] = c.dd[k0 + lk + 4 * q];
+        A[(i0 + li) + (k0 + lk + 4 * q) * lda] = l[q];
+      }
+      lds_flag_set(&flags[PF_LRDY + I], kb + 1);
+      if (c.Xa && i0 + li < w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) post_f64(c.Xa + (i0 + li) + (k0 + lk + 4 * q) * wp, l[q]);
+      }
+      if (kb == 0) lds_flag_wait_ge(&flags[PF_STAGE2], 7, info);  // the tiles right of block column 0 were loaded by everybody
+      // own diagonal tile first (needs nothing from the other rows), then the tiles J = kb+1 .. I-1
+      for (int jj = 0; jj <= I - kb - 1; ++jj) {
+        const int J = (jj == 0) ? I : kb + jj;
+        const int j0 = J << 4;
+        d4_t t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = A[(i0 + lk + 4 * q) + (j0 + li) * lda];
+        if (J < I) {
+          lds_flag_wait_ge(&flags[PF_LRDY + J], kb + 1, info);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) t = MFMA_F64(l[s], -(A[(j0 + li) + (k0 + lk + 4 * s) * lda] * dk[s]), t);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) t = MFMA_F64(l[s], -y[s], t);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[(i0 + lk + 4 * q) + (j0 + li) * lda] = t[q];
+      }
+      lds_flag_set(&flags[PF_UPD + I], kb + 1);
+#ifdef HIPFACT_TRACE
+      if (lane == 0 && kb + 2 == I && blockIdx.x < TRACE_WGS) g_own[blockIdx.x * 8 + I] = wall_clock64();
+#endif
+    }
+  }
+  // The inverses of the diagonal blocks and the pivots are posted to the panel workgroups by wave 4: five LDS reads
+  // and stores per block that the chain wave does not have to issue.
+  if (c.Xa && wave == 4) {
+    for (int kb = 0; kb < nbk; ++kb) {
+      lds_flag_wait_ge(&flags[PF_DIAG], kb + 1, info);
+      dev_pivot_post_diag(c, kb << 4);
+    }
+  }
+}
+
 // store inv(L11) (strict lower) and the pivots (diagonal) back to the panel
 __device__ __forceinline__ void dev_store_pivot_block(const FrontCtx& c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1128,6 +1351,9 @@ __device__ __forceinline__ void dev_load_pivot_block(const FrontCtx& c, bool nee
 
 // rows R0 + li of the panel: all fragments in one batch of loads (w <= 128: 32 values per lane),
 // plus the children's rows that land on them (pull mode)
+// DL: element (tt, s) of a lane is column 16 tt + lk + 4 s (the accumulator layout of the matrix cores, rows of the
+// transposed block) instead of 16 tt + 4 s + lk (the B operand layout)
+template <bool DL = false>
 __device__ __forceinline__ void dev_panel_rows_load(const FrontCtx& c, int R0, const PullCtx& pc, double (&pv)[8][4],
                                                     int (&cis)[MAXCH]) {
   const int lane = threadIdx.x & 63;
@@ -1141,13 +1367,14 @@ __device__ __forceinline__ void dev_panel_rows_load(const FrontCtx& c, int R0, c
   for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int col = 16 * tt + 4 * s + lk;
+      const int col = 16 * tt + (DL ? lk + 4 * s : 4 * s + lk);
       pv[tt][s] = (rok && col < w) ? Prow[(long long)col * r] : 0.0;
     }
 }
 
 // gathers (pull mode), X P21^T on the MFMA units, scaling by D^-1, row-contiguous stores
 // the children's rows that land on the panel rows R0 + li (pull mode), added in child order
+template <bool DL = false>
 __device__ __forceinline__ void dev_panel_rows_gather(const FrontCtx& c, const PullCtx& pc, const int* invl,
                                                       double (&pv)[8][4], const int (&cis)[MAXCH]) {
   const int lane = threadIdx.x & 63;
@@ -1165,7 +1392,7 @@ __device__ __forceinline__ void dev_panel_rows_gather(const FrontCtx& c, const P
       for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int col = 16 * tt + 4 * s + lk;
+          const int col = 16 * tt + (DL ? lk + 4 * s : 4 * s + lk);
           const int cj = (tt < nbk && ci >= 0) ? invl[ch * c.wp + col] : -1;
           const double gv = Uc[(cj >= 0) ? ci + (long long)cj * uc : 0];
           g[tt][s] = (cj >= 0) ? gv : 0.0;
@@ -1270,6 +1497,142 @@ __device__ __forceinline__ void dev_panel_rows_product_posted(const FrontCtx& c,
         }
       }
     }
+  }
+}
+
+
+// Panel rows in the single-launch factorisation, V2: the pivot workgroup posts the tiles of L11 itself (unit lower
+// factor: tile (I, kb) right after step kb, the inverse of the diagonal block kb and its pivots after diag(kb)) and no
+// longer forms inv(L11) on the critical path.  The panel is solved by block substitution, transposed so that a wave's
+// finished blocks are at once the B operands of the later ones: with W = L21 D,  L11 W^T = P21^T, i.e.
+//   W^T[ct] = X_ct (P21^T[ct] - sum_{tt < ct} L11[ct, tt] W^T[tt]),   X_ct = inv(L11[ct, ct]),
+// every accumulator (rows lk + 4 q of the block = columns of L21, column li = panel row) serves as operand with k
+// running as lk + 4 s.  Block row ct of L11 is complete when diag(ct) has been posted, so the panel follows the pivot
+// workgroup block by block and 8 dependent matrix instructions remain when the pivot block is done.  pv: the wave's
+// 16 panel rows in the accumulator layout (dev_panel_rows_load<true>), overwritten by W^T.
+// store_d: this workgroup also writes the pivots it polled onto the diagonal of the panel.  The Schur workgroups read
+// d_k from there once the PANEL workgroups have published, and the pivot workgroup - busy inverting L11 behind its
+// chain - stores its copy (the same bits) only later.
+__device__ __forceinline__ void dev_panel_rows_subst_posted(const FrontCtx& c, int R0, double (&pv)[8][4], bool active,
+                                                            bool store_d, int* __restrict__ info) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = c.w, r = c.r, nbk = c.nbk, lda = c.lda, wp = c.wp;
+  double* A = c.A;
+  double* __restrict__ P = c.P;
+  const bool rok = active && (R0 + li) < r;
+  // Polling: thread t owns position (pi, pk) of the tiles tq, tq + 2, tq + 4, tq + 6 of every block row, four requests
+  // per block row that leave together (a poll per element would be a memory round trip each); what still holds the
+  // sentinel is requested again, pass after pass.  The requests for block row ct + 1 are issued before the matrix work
+  // of row ct and stay in flight across it.  (Kept to a few dozen instructions per row: with eight waves on four
+  // SIMDs a wave issues one instruction per ~8 clocks, and a general element -> thread map with per-element
+  // predicates cost more than the round trips it saved.)
+  constexpr int NB = 4;
+  constexpr unsigned long long ONE = 0x3FF0000000000000ull;
+  const int pi = tid & 15, pk = (tid >> 4) & 15, tq = tid >> 8;
+  const unsigned long long* xbase = reinterpret_cast<const unsigned long long*>(c.Xa) + pi + pk * wp;
+  const unsigned long long* xdiag = reinterpret_cast<const unsigned long long*>(c.Xa) + tid * (wp + 1);
+  unsigned long long nb[8][NB], nd[8];
+  auto addr = [&](int cr, int b2) { return xbase + 16 * cr + 16 * (tq + 2 * b2) * wp; };
+  auto need = [&](int cr, int b2) {
+    const int tt = tq + 2 * b2;
+    return 16 * cr + pi < w && (tt < cr || (tt == cr && pk < pi));
+  };
+  // A panel workgroup gets going ~8 us after the pivot workgroup (its own rows and the children's contributions are four
+  // dependent round trips): the block rows posted by then are all requested at once, before the first one is used
+#pragma unroll
+  for (int cr = 0; cr < 8; ++cr) {
+    if (cr >= nbk) break;
+#pragma unroll
+    for (int b2 = 0; b2 < NB; ++b2) {
+      const int tt = tq + 2 * b2;
+      nb[cr][b2] = need(cr, b2) ? __hip_atomic_load(addr(cr, b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : ((tt == cr && pk == pi) ? ONE : 0ull);  // unit diagonal, zero padding
+    }
+    nd[cr] = (tid < 16 && 16 * cr + tid < w) ? __hip_atomic_load(xdiag + 16 * cr * (wp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ONE;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) {  // (unrolled: pv, nb, nd are indexed by ct and must stay in registers)
+    if (ct >= nbk) break;
+    // block row ct of L11: tiles (ct, 0 .. ct-1), the inverse of the diagonal block (unit diagonal), 1 / d of its pivots
+    for (int spins = 0;; ++spins) {
+      bool again = false;
+#pragma unroll
+      for (int b2 = 0; b2 < NB; ++b2)
+        if (nb[ct][b2] == SOLVE_SENT) {
+          nb[ct][b2] = __hip_atomic_load(addr(ct, b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          again = true;
+        }
+      if (nd[ct] == SOLVE_SENT) {
+        nd[ct] = __hip_atomic_load(xdiag + 16 * ct * (wp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        again = true;
+      }
+      if (!again) break;
+      if (spins > (1 << 20)) {
+        atomicAdd(&info[INFO_TIMEOUT], 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < NB; ++b2) {
+      const int tt = tq + 2 * b2;
+      if (tt <= ct) A[(16 * ct + pi) + (16 * tt + pk) * lda] = __longlong_as_double((long long)nb[ct][b2]);
+    }
+    if (tid < 16) {
+      const int col = 16 * ct + tid;
+      const double d = __longlong_as_double((long long)nd[ct]);
+      c.dd[col] = 1.0 / d;
+      if (store_d && col < w) P[col + (long long)col * r] = d;
+    }
+    TRP(8 + ct);
+    __syncthreads();
+    TRP(ct);
+    // what was not there yet of the next block row is requested again; in flight across the matrix work of this one
+    if (ct + 1 < nbk) {
+#pragma unroll
+      for (int b2 = 0; b2 < NB; ++b2)
+        if (nb[ct + 1 < 8 ? ct + 1 : 7][b2] == SOLVE_SENT)
+          nb[ct + 1 < 8 ? ct + 1 : 7][b2] = __hip_atomic_load(addr(ct + 1, b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nd[ct + 1 < 8 ? ct + 1 : 7] == SOLVE_SENT)
+        nd[ct + 1 < 8 ? ct + 1 : 7] = __hip_atomic_load(xdiag + 16 * (ct + 1) * (wp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (active) {
+      // operands first (one batch of LDS reads), then the matrix instructions on four accumulators, one per k
+      // group: a dependent matrix instruction waits for its predecessor's result, and so does one behind a load
+      double lv[8][4], xv[4];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt)
+        if (tt < ct) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) lv[tt][s] = -A[(16 * ct + li) + (16 * tt + lk + 4 * s) * lda];
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xv[s] = A[(16 * ct + li) + (16 * ct + lk + 4 * s) * lda];
+      d4_t acc = {pv[ct][0], pv[ct][1], pv[ct][2], pv[ct][3]};
+      d4_t ac[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt)
+        if (tt < ct) {
+          acc = MFMA_F64(lv[tt][0], pv[tt][0], acc);
+#pragma unroll
+          for (int s = 1; s < 4; ++s) ac[s - 1] = MFMA_F64(lv[tt][s], pv[tt][s], ac[s - 1]);
+        }
+      if (ct > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += (ac[0][q] + ac[1][q]) + ac[2][q];
+      }
+      d4_t res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) res = MFMA_F64(xv[s], acc[s], res);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pv[ct][q] = res[q];
+        const int col = 16 * ct + lk + 4 * q;
+        if (rok && col < w) P[(R0 + li) + (long long)col * r] = res[q] * c.dd[col];
+      }
+    }
+    TRP(16 + ct);
   }
 }
 
@@ -1395,7 +1758,9 @@ __device__ __forceinline__ void dev_schur_tile(const FrontCtx& c, double* SI, do
     }
     __syncthreads();
     if (!idle) schur_tile_gather(pc, invs, i0, j0, li, lk, uv);
+    TRW(5);
     flag_wait_ge(wait_addr, wait_target, info);
+    TRW(1);
   }
   const int si = tid & 63;
   const bool iok = !ghost && (64 * I + si) < u, jok = !ghost && (64 * J + si) < u;
@@ -1532,7 +1897,9 @@ __device__ __forceinline__ void dev_schur_tile32(const FrontCtx& c, int I, int J
         for (int q = 0; q < 4; ++q) uv[q] += g[q];
       }
   }
+  TRW(5);
   flag_wait_ge(wait_addr, wait_target, info);
+  TRW(1);
   // both strips in one batch: element e -> (k = e / 64, strip = (e / 32) & 1, row = e % 32)
   {
     double v[16], d[16];  // 64 wp <= 8192 elements
@@ -1630,7 +1997,12 @@ __global__ __launch_bounds__(512) void k_front_pivot(const FrontItem* __restrict
   const FrontItem& S = items[blockIdx.x];
   const FrontCtx c = make_ctx(S, L, U, lds);
   const PullCtx pc = make_pull(S.pd, U, inv, rel, pull);
+#ifdef HIPFACT_PIVOT_V1
   dev_pivot_block<true, CHAIN>(c, info, 15, pc, no_wait(), PullMore{more, U, inv, rel});  // stores the finished tiles itself
+#else
+  dev_pivot_block<false, CHAIN, true>(c, info, 15, pc, no_wait(), PullMore{more, U, inv, rel});
+  dev_store_pivot_block(c);
+#endif
 }
 
 // LDS: dd | X | MAXCH x wp ints (the children's inverse maps of the pivot columns)
@@ -2291,6 +2663,10 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TopFItem& T = items[blockIdx.x];
   const FrontItem& S = T.it;
+  TRW(0);
+#ifdef HIPFACT_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_trace[blockIdx.x * 8 + 7] = T.role * 100000 + T.front;
+#endif
   if (T.role == 3) {
     if (T.nwait) {  // a front of this launch: pivot block and every panel workgroup
       if (threadIdx.x == 0) {
@@ -2308,7 +2684,12 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
       }
       __syncthreads();
     }
+    TRW(1);
     dev_build_solve_panel(sitems[S.part], L, SPf, SPb, lds);
+#ifdef HIPFACT_TRACE
+    __syncthreads();
+#endif
+    TRW(2);
     return;
   }
   FrontCtx c = make_ctx(S, L, U, lds);
@@ -2328,8 +2709,15 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
   // In every role, whatever does not depend on the awaited workgroups is requested before the
   // wait, so that afterwards only the awaited data is one memory round trip away.
   if (T.role == 0) {
+#ifdef HIPFACT_PIVOT_V1
     dev_pivot_block<true>(c, info, 15, pc, cw);  // waits for the children between its prefetch and its gathers
+#else
+    dev_pivot_block<false, false, true>(c, info, 15, pc, cw);  // waits for the children between its prefetch and its gathers
+    dev_store_pivot_block(c);                                  // inv(L11) and the pivots: the factor's final form
+#endif
+    TRW(2);
     flag_publish_add(&bdone[T.front]);
+    TRW(3);
     // A front without update rows (the root): its solve panel is X and the pivots, both still in LDS - written here
     // instead of by an item of its own that could only start now (same expressions, same bits)
     if (T.sidx > 0) {
@@ -2360,10 +2748,26 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
         for (int k = threadIdx.x; k < c.wp; k += blockDim.x) invl[ch * c.wp + k] = (k < c.w) ? pc.inv[ch][k] : -1;
     // crows = 128: one 16-row strip per wave; 64: two waves per strip, alternating output blocks
     const int wv = threadIdx.x >> 6;
-    const int cstep = T.crows == 64 ? 2 : 1;
-    const int R0 = c.w + T.crows * S.part + 16 * (cstep == 2 ? (wv >> 1) : wv);
+    const int cstep = T.prows == 64 ? 2 : 1;
+    const int R0 = c.w + T.prows * S.part + 16 * (cstep == 2 ? (wv >> 1) : wv);
     double pv[8][4];
     int cis[MAXCH];
+#ifndef HIPFACT_PIVOT_V1
+    if (c.Xa) {  // the pivot workgroup posts L11: block substitution, one wave per strip of 16 rows
+      const bool mine = 16 * wv < T.prows;  // (prows = 64: the waves 4 .. 7 only poll and stage)
+      const int R1 = c.w + T.prows * S.part + 16 * wv;
+      const int Rs = mine ? R1 : c.r;       // (an idle wave loads nothing)
+      dev_panel_rows_load<true>(c, Rs, pc, pv, cis);
+      __syncthreads();
+      dev_panel_rows_gather<true>(c, pc, invl, pv, cis);
+      TRW(1);
+      dev_panel_rows_subst_posted(c, Rs, pv, mine && R1 < c.r, S.part == 0, info);
+      TRW(2);
+      flag_publish_add(&cdone[T.front]);
+      TRW(3);
+      return;
+    }
+#endif
     dev_panel_rows_load(c, R0, pc, pv, cis);
     __syncthreads();
     dev_panel_rows_gather(c, pc, invl, pv, cis);
@@ -2392,7 +2796,9 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     // to the sentinel for the next factorisation (a share per Schur workgroup)
     if (c.Xa)
       for (int e = T.sidx * 512 + threadIdx.x; e < c.wp * c.wp; e += T.scount * 512) sent_f64(c.Xa + e);
+    TRW(2);
     flag_publish_add(&ddone[T.front]);
+    TRW(3);
   }
 }
 

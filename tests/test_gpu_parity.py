@@ -559,6 +559,10 @@ def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
     N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
     b = np.random.default_rng(1).standard_normal(N)
     fact.set_option("refine_steps", 0)
+    # per-level launches in all three runs: the dataflow launch (pull mode only) solves its panels by block
+    # substitution against the posted L11, the per-level panel kernel multiplies by inv(L11) - equal to rounding only
+    # (test_single_launch_top_of_tree_factorisation_agrees); what is compared bit for bit here is the extend-add
+    fact.set_option("factor_top_max", 0)
     outs = []
     for pull in (0, 4, 2):
         fact.set_option("pull_max_children", pull)
@@ -568,11 +572,20 @@ def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     K = synth.kkt_full_matrix(N, kc, kr, kd)
     assert scaled_residual(K, outs[0], b) <= 1e-9
+    fact.set_option("factor_top_max", 128)
 
 
-def test_single_launch_top_of_tree_factorisation_agrees_bitwise(fact):
-    """Per-level pivot / panel / Schur launches and the single dataflow launch for the top
-    levels run the same device code on the same data: identical bits."""
+def _agree(a, b, tol=1e-11):
+    """Two schedules of the same factorisation whose panels are formed by different (backward stable) formulas:
+    L21 = P21 inv(L11)^T D^-1 as a product with the inverse, or by block substitution against L11."""
+    return np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(a)))
+
+
+def test_single_launch_top_of_tree_factorisation_agrees(fact):
+    """Per-level pivot / panel / Schur launches and the single dataflow launch for the top levels.  Same pivot
+    block code and same Schur updates; the panel workgroups of the dataflow launch follow the tiles of L11 the
+    pivot workgroup posts and solve by block substitution, the per-level panel kernel multiplies by inv(L11):
+    agreement to rounding (no refinement: 1e-11 of the solution), and every schedule is bitwise reproducible."""
     from sleqp_amd.sparse import SleqpMat
 
     n, m = 12000, 6000
@@ -591,7 +604,10 @@ def test_single_launch_top_of_tree_factorisation_agrees_bitwise(fact):
         fact.solve(b)
         outs.append(fact.solution_raw(0, N))
         assert fact.info("solve_timeouts") == 0
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        fact.solve(b)
+        assert np.array_equal(outs[-1], fact.solution_raw(0, N))  # the schedule itself is deterministic
+    assert _agree(outs[0], outs[1]) and _agree(outs[0], outs[2])
     K = synth.kkt_full_matrix(N, kc, kr, kd)
     assert scaled_residual(K, outs[0], b) <= 1e-9
 
@@ -810,8 +826,9 @@ def test_deferred_refinement_verdict(fact):
 def test_dense_chain_levels_as_small_dataflow_launches(fact):
     """Single-front levels of a dense chain below the top-of-tree launch run their pivot and panel items as ONE
     small dataflow launch (panel workgroups following the posted pivot block) instead of two launches; the sliced
-    fronts of the two-launch solves exchange posted data instead of flags.  Same arithmetic: same bits as the
-    per-level kernels, over repeated factorisations (the posted slots are refilled with the sentinel each time)."""
+    fronts of the two-launch solves exchange posted data instead of flags.  Agreement with the per-level kernels to
+    rounding (substitution against the posted L11 / product with inv(L11)), bitwise reproducible over repeated
+    factorisations (the posted slots are refilled with the sentinel each time)."""
     from sleqp_amd.sparse import SleqpMat
 
     J = synth.uniform_jacobian(3000, 1500, 10, 9)  # dense Schur complement: a chain of single-front levels
@@ -834,7 +851,7 @@ def test_dense_chain_levels_as_small_dataflow_launches(fact):
             assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
         outs[fuse] = res
     for a, b_ in zip(outs[1], outs[0]):
-        assert np.array_equal(a, b_)
+        assert _agree(a, b_, 1e-10)
     assert np.array_equal(outs[1][0], outs[1][2]) and np.array_equal(outs[1][1], outs[1][5])
     assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-8
     fact.set_option("chain_fuse", 1)
