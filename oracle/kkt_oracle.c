@@ -248,6 +248,110 @@ int oracle_fill_aug_jac(int num_variables, int num_constraints, const int* cons_
 
 /* store_matrix_values, fact_lapack.c:52-73: symmetric densification of the
  * lower-triangular CSC K into an N x N array (zeroed first, :100-103). */
+/* ---------------------------------------------------------------------------
+ * Reduced AugJac: the matrix A_W A_W^T handed to a PSD-flagged backend.
+ * Restates aug_jac/reduced_aug_jac.c: the CSR copy of the working-set rows (count_rows :112-191, fill_system
+ * :193-262: unit rows of the active variables first, then the constraint rows in the column order of cons_jac) and
+ * compute_matrix_lower (:323-377) with compute_inner_product (:283-321).  Faithful to the reference in one
+ * noteworthy detail: compute_inner_product starts from *nonzero = true (:290), so EVERY entry below the diagonal is
+ * pushed, zero products included - the matrix the backend receives is a dense lower triangle.
+ * Output: lower CSC (cols[size + 1], rows, data) with capacity size (size + 1) / 2; returns nnz.
+ * ------------------------------------------------------------------------- */
+int oracle_reduced_aug_jac(int num_variables, int num_constraints, const int* cons_jac_cols, const int* cons_jac_rows,
+                           const double* cons_jac_data, const int* var_index, const int* cons_index,
+                           int working_set_size, int* out_cols, int* out_rows, double* out_data)
+{
+  const int size = working_set_size;
+  int num_active_vars = 0;
+  for (int j = 0; j < num_variables; ++j) num_active_vars += (var_index[j] >= 0);
+  /* count_rows */
+  int* row_counts = (int*)calloc((size_t)size + 2, sizeof(int));
+  int nnz = num_active_vars;
+  for (int i = 0; i < num_active_vars; ++i) row_counts[i] = 1;
+  for (int col = 0; col < num_variables; ++col)
+    for (int index = cons_jac_cols[col]; index < cons_jac_cols[col + 1]; ++index)
+    {
+      const int cons = cons_index[cons_jac_rows[index]];
+      if (cons < 0) continue;
+      ++row_counts[cons];
+      ++nnz;
+    }
+  int offset = 0;
+  for (int i = 0; i <= size; ++i)
+  {
+    const int current = row_counts[i];
+    row_counts[i]     = offset;
+    offset += current;
+  }
+  /* fill_system */
+  int* col_indices = (int*)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  double* values   = (double*)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  int* row_offsets = (int*)calloc((size_t)size + 1, sizeof(int));
+  for (int i = 0; i < num_active_vars; ++i) values[i] = 1.;
+  for (int j = 0; j < num_variables; ++j)
+    if (var_index[j] >= 0) col_indices[var_index[j]] = j;
+  for (int col = 0; col < num_variables; ++col)
+    for (int index = cons_jac_cols[col]; index < cons_jac_cols[col + 1]; ++index)
+    {
+      const int cons = cons_index[cons_jac_rows[index]];
+      if (cons < 0) continue;
+      const int jac_index    = row_counts[cons] + row_offsets[cons];
+      values[jac_index]      = cons_jac_data[index];
+      col_indices[jac_index] = col;
+      ++row_offsets[cons];
+    }
+  /* compute_matrix_lower */
+  int out = 0;
+  for (int col = 0; col < size; ++col)
+  {
+    out_cols[col] = out;
+    if (col < num_active_vars)
+    {
+      out_rows[out] = col;
+      out_data[out] = 1.;
+      ++out;
+    }
+    else
+    {
+      double product = 0.;
+      for (int k = row_counts[col]; k < row_counts[col + 1]; ++k) product += values[k] * values[k];
+      out_rows[out] = col;
+      out_data[out] = product;
+      ++out;
+    }
+    for (int row = col + 1; row < size; ++row)
+    {
+      double product = 0.;
+      int col_index = row_counts[col], row_index = row_counts[row];
+      const int col_bound = row_counts[col + 1], row_bound = row_counts[row + 1];
+      while (col_index < col_bound && row_index < row_bound)
+      {
+        const int col_col = col_indices[col_index], row_col = col_indices[row_index];
+        if (row_col < col_col)
+          ++row_index;
+        else if (row_col > col_col)
+          ++col_index;
+        else
+        {
+          product += values[row_index] * values[col_index];
+          ++row_index;
+          ++col_index;
+        }
+      }
+      out_rows[out] = row; /* nonzero is always true in the reference (:290) */
+      out_data[out] = product;
+      ++out;
+    }
+  }
+  out_cols[size] = out;
+  free(row_counts);
+  free(col_indices);
+  free(values);
+  free(row_offsets);
+  (void)num_constraints;
+  return out;
+}
+
 void oracle_lapack_store_matrix_values(int num_cols, const int* cols, const int* rows, const double* data,
                                        double* values)
 {

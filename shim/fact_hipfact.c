@@ -48,7 +48,89 @@ typedef struct
   int slice_size;
 
   int num_rows;
+
+  /* counters of the handle at the last look (debug log of what a call cost) */
+  double seen_analyses, seen_swaps, seen_fallbacks, seen_hits, seen_refine;
+
+  bool psd; /* created by sleqp_fact_hipfact_psd_create */
 } HipFactData;
+
+#ifdef HIPFACT_STANDALONE
+/* harness only: the handle behind the backend created last (the tests read
+ * hipfact_get_info through it; SleqpFact keeps its fact_data private) */
+static hipfact_handle* last_handle = NULL;
+hipfact_handle*
+sleqp_fact_hipfact_last_handle(void)
+{
+  return last_handle;
+}
+#endif
+
+/* What a call did inside the library, at debug level (the pattern is
+ * aug_jac.c:45-76: the reference wraps its callbacks in timers; here the
+ * interesting events are symbolic analyses, plan swaps, fallbacks of the
+ * dataflow launches and refinement passes behind the first) */
+static void
+hipfact_log_events(HipFactData* data, const char* where)
+{
+  if (sleqp_log_level() < SLEQP_LOG_DEBUG)
+  {
+    return;
+  }
+
+  double analyses = 0., swaps = 0., fallbacks = 0., hits = 0., refine = 0.;
+  double analysis_s = 0., nlevels = 0., nsuper = 0., maps = 0.;
+
+  hipfact_get_info(data->handle, "analyses", &analyses);
+  hipfact_get_info(data->handle, "plan_swaps", &swaps);
+  hipfact_get_info(data->handle, "dataflow_fallbacks", &fallbacks);
+  hipfact_get_info(data->handle, "cache_hits", &hits);
+  hipfact_get_info(data->handle, "num_refined", &refine);
+
+  if (analyses != data->seen_analyses)
+  {
+    hipfact_get_info(data->handle, "analysis_s", &analysis_s);
+    hipfact_get_info(data->handle, "nlevels", &nlevels);
+    hipfact_get_info(data->handle, "nsuper", &nsuper);
+    hipfact_get_info(data->handle, "maps_on", &maps);
+    sleqp_log_debug("hipfact %s: symbolic analysis #%d (%.1f ms, %d fronts on "
+                    "%d levels, %s structure)",
+                    where,
+                    (int)analyses,
+                    1e3 * analysis_s,
+                    (int)nsuper,
+                    (int)nlevels,
+                    maps != 0. ? "working-set superset" : "exact");
+  }
+  else if (swaps != data->seen_swaps)
+  {
+    sleqp_log_debug("hipfact %s: cached plan swapped in (%d swaps, %d cache "
+                    "hits so far)",
+                    where,
+                    (int)swaps,
+                    (int)hits);
+  }
+  if (fallbacks != data->seen_fallbacks)
+  {
+    sleqp_log_debug("hipfact %s: a dataflow launch timed out, per-level "
+                    "launches from now on (%s)",
+                    where,
+                    hipfact_last_error(data->handle));
+  }
+  if (refine != data->seen_refine)
+  {
+    sleqp_log_debug("hipfact %s: iterative refinement continued behind the "
+                    "passes the solve graph carries (%d solves so far)",
+                    where,
+                    (int)refine);
+  }
+
+  data->seen_analyses  = analyses;
+  data->seen_swaps     = swaps;
+  data->seen_fallbacks = fallbacks;
+  data->seen_hits      = hits;
+  data->seen_refine    = refine;
+}
 
 #define HIPFACT_CALL(data, x)                                                  \
   do                                                                           \
@@ -57,9 +139,15 @@ typedef struct
     if (hipfact_status != HIPFACT_OK)                                          \
     {                                                                          \
       sleqp_raise(SLEQP_INTERNAL_ERROR,                                        \
-                  "Caught hipfact error <%d> (%s)",                            \
+                  "Caught hipfact error <%d> (%s)%s",                          \
                   hipfact_status,                                              \
-                  hipfact_last_error((data)->handle));                         \
+                  hipfact_last_error((data)->handle),                          \
+                  hipfact_status == HIPFACT_ESINGULAR                          \
+                    ? " - hipfact factors with a static pivot order and "      \
+                      "reports a rank-deficient working set where MA57 "       \
+                      "would delay pivots (pub_working_set.h:42-44 excludes "  \
+                      "such working sets)"                                     \
+                    : "");                                                     \
     }                                                                          \
   } while (0)
 
@@ -89,6 +177,8 @@ hipfact_fact_set_matrix(void* fact_data, SleqpMat* matrix)
                                   sleqp_mat_cols(matrix),
                                   sleqp_mat_rows(matrix),
                                   sleqp_mat_data(matrix)));
+
+  hipfact_log_events(data, "set_matrix");
 
   return SLEQP_OKAY;
 }
@@ -123,6 +213,8 @@ hipfact_fact_solution(void* fact_data,
 
   HIPFACT_CALL(data, hipfact_solution(data->handle, data->slice, begin, end));
 
+  hipfact_log_events(data, "solution");
+
   SLEQP_CALL(sleqp_vec_set_from_raw(sol, data->slice, end - begin, zero_eps));
 
   return SLEQP_OKAY;
@@ -147,6 +239,13 @@ hipfact_fact_free(void** star)
   {
     return SLEQP_OKAY;
   }
+
+#ifdef HIPFACT_STANDALONE
+  if (last_handle == data->handle)
+  {
+    last_handle = NULL;
+  }
+#endif
 
   hipfact_free(&data->handle);
 
@@ -182,6 +281,10 @@ hipfact_data_create(HipFactData** star)
                 message);
   }
 
+#ifdef HIPFACT_STANDALONE
+  last_handle = data->handle;
+#endif
+
   return SLEQP_OKAY;
 }
 
@@ -204,6 +307,42 @@ sleqp_fact_hipfact_create(SleqpFact** star, SleqpSettings* settings)
                                settings,
                                &callbacks,
                                SLEQP_FACT_FLAGS_LOWER,
+                               (void*)data));
+
+  return SLEQP_OKAY;
+}
+
+/* The PSD flavour (pattern: fact_cholmod.c:15, 231-262): declares
+ * SLEQP_FACT_FLAGS_PSD | SLEQP_FACT_FLAGS_LOWER, so that create_aug_jac
+ * (trial_point.c:94-101) puts the REDUCED AugJac in front of it and the matrix
+ * handed over is the lower triangle of the symmetric positive definite
+ * A_W A_W^T (reduced_aug_jac.c:323-377, 473).  Inside the library this is the
+ * generic mode: the same supernodal engine on M = K with static 1x1 pivots. */
+SLEQP_RETCODE
+sleqp_fact_hipfact_psd_create(SleqpFact** star, SleqpSettings* settings)
+{
+  SleqpFactCallbacks callbacks = {.set_matrix = hipfact_fact_set_matrix,
+                                  .solve      = hipfact_fact_solve,
+                                  .solution   = hipfact_fact_solution,
+                                  .condition  = hipfact_fact_condition,
+                                  .free       = hipfact_fact_free};
+
+  HipFactData* data = NULL;
+
+  SLEQP_CALL(hipfact_data_create(&data));
+
+  data->psd = true;
+
+  /* never the saddle interpretation, whatever the pattern looks like */
+  HIPFACT_CALL(data, hipfact_set_option(data->handle, "force_generic", 1.));
+  HIPFACT_CALL(data, hipfact_set_option(data->handle, "superset_vtable", 0.));
+
+  SLEQP_CALL(sleqp_fact_create(star,
+                               SLEQP_FACT_HIPFACT_NAME "-psd",
+                               SLEQP_FACT_HIPFACT_VERSION,
+                               settings,
+                               &callbacks,
+                               SLEQP_FACT_FLAGS_PSD | SLEQP_FACT_FLAGS_LOWER,
                                (void*)data));
 
   return SLEQP_OKAY;

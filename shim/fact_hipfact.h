@@ -15,4 +15,10 @@ SLEQP_WARNUNUSED
 SLEQP_RETCODE
 sleqp_fact_hipfact_create(SleqpFact** star, SleqpSettings* settings);
 
+/* PSD | LOWER: the backend behind the reduced AugJac (A_W A_W^T, symmetric
+ * positive definite; pattern fact_cholmod.c:231-262) */
+SLEQP_WARNUNUSED
+SLEQP_RETCODE
+sleqp_fact_hipfact_psd_create(SleqpFact** star, SleqpSettings* settings);
+
 #endif /* SLEQP_FACT_HIPFACT_H */

@@ -20,6 +20,49 @@ sleqp_error_type(void) { return g_error_type; }
 const char*
 sleqp_error_msg(void) { return g_error_msg; }
 
+/* ---- log (log.c): global level + handler; the harness keeps the messages for the tests */
+static SLEQP_LOG_LEVEL g_log_level = SLEQP_LOG_INFO;
+static SLEQP_LOG_HANDLER g_log_handler = NULL;
+static char g_log_buf[1 << 16];
+static char g_log_out[1 << 16];
+static size_t g_log_len = 0;
+SLEQP_LOG_LEVEL
+sleqp_log_level(void) { return g_log_level; }
+void
+sleqp_log_set_level(SLEQP_LOG_LEVEL level) { g_log_level = level; }
+void
+sleqp_log_set_handler(SLEQP_LOG_HANDLER handler) { g_log_handler = handler; }
+void
+sleqp_log_msg_level(int level, const char* fmt, ...)
+{
+  char msg[2048];
+  va_list args;
+  va_start(args, fmt);
+  vsnprintf(msg, sizeof msg, fmt, args);
+  va_end(args);
+  if (g_log_handler)
+  {
+    g_log_handler((SLEQP_LOG_LEVEL)level, time(NULL), msg);
+  }
+  const size_t len = strlen(msg);
+  if (g_log_len + len + 2 < sizeof g_log_buf)
+  {
+    memcpy(g_log_buf + g_log_len, msg, len);
+    g_log_len += len;
+    g_log_buf[g_log_len++] = '\n';
+    g_log_buf[g_log_len]   = 0;
+  }
+}
+const char*
+sleqp_mini_log_drain(void)
+{
+  memcpy(g_log_out, g_log_buf, g_log_len + 1);
+  g_log_out[g_log_len] = 0;
+  g_log_len            = 0;
+  g_log_buf[0]         = 0;
+  return g_log_out;
+}
+
 void
 sleqp_set_error(const char* file, int line, const char* func, SLEQP_ERROR_TYPE error_type, const char* fmt, ...)
 {

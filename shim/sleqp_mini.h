@@ -50,6 +50,42 @@ SLEQP_ERROR_TYPE
 sleqp_error_type(void);
 const char*
 sleqp_error_msg(void);
+
+/* pub_log.h:9-95: levels, global level / handler, the sleqp_log_* macros */
+typedef enum
+{
+  SLEQP_LOG_SILENT     = 0,
+  SLEQP_LOG_ERROR      = 1,
+  SLEQP_LOG_WARN       = 2,
+  SLEQP_LOG_INFO       = 3,
+  SLEQP_LOG_DEBUG      = 4,
+  SLEQP_NUM_LOG_LEVELS = 5
+} SLEQP_LOG_LEVEL;
+#include <time.h>
+typedef void (*SLEQP_LOG_HANDLER)(SLEQP_LOG_LEVEL level, time_t time, const char* message);
+SLEQP_LOG_LEVEL
+sleqp_log_level(void);
+void
+sleqp_log_set_level(SLEQP_LOG_LEVEL level);
+void
+sleqp_log_set_handler(SLEQP_LOG_HANDLER handler);
+void
+sleqp_log_msg_level(int level, const char* fmt, ...);
+#define sleqp_log_log_msg(level, ...)                                          \
+  do                                                                           \
+  {                                                                            \
+    if (sleqp_log_level() >= level)                                            \
+    {                                                                          \
+      sleqp_log_msg_level(level, __VA_ARGS__);                                 \
+    }                                                                          \
+  } while (0)
+#define sleqp_log_info(...) sleqp_log_log_msg(SLEQP_LOG_INFO, __VA_ARGS__)
+#define sleqp_log_warn(...) sleqp_log_log_msg(SLEQP_LOG_WARN, __VA_ARGS__)
+#define sleqp_log_error(...) sleqp_log_log_msg(SLEQP_LOG_ERROR, __VA_ARGS__)
+#define sleqp_log_debug(...) sleqp_log_log_msg(SLEQP_LOG_DEBUG, __VA_ARGS__)
+/* harness only: the messages logged so far (newline separated), cleared by the call */
+const char*
+sleqp_mini_log_drain(void);
 void
 sleqp_set_error(const char* file, int line, const char* func, SLEQP_ERROR_TYPE error_type, const char* fmt, ...)
   __attribute__((__format__(__printf__, 5, 6)));

@@ -631,11 +631,9 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   for (int s = 0; s < ns; ++s) {
     std::copy(sn[s].rows.begin(), sn[s].rows.end(), P.sn_rows.begin() + P.sn_rowptr[s]);
     const int w = sn[s].w, r = P.sn_r[s], u = r - w;
-    P.sn_Loff[s] = Loff;
     P.sn_Uoff[s] = Uoff;
     P.sn_uoff[s] = uoff;
     // keep every panel / update matrix 16-byte aligned (even number of doubles)
-    Loff += ((int64_t)r * w + 1) & ~1LL;
     Uoff += ((int64_t)u * u + 1) & ~1LL;
     uoff += (u + 1) & ~1;
     P.rel_ptr[s + 1] = P.rel_ptr[s] + u;
@@ -646,7 +644,6 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     P.max_w = std::max(P.max_w, w);
     P.max_u = std::max(P.max_u, u);
   }
-  P.L_size = Loff;
   P.U_size = Uoff;
   P.u_size = uoff;
   // children, levels
@@ -683,6 +680,16 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
                          return wa > wb;
                        });
   }
+  // Panels in LEVEL order: the fronts below any level form a prefix of the factor arena.  (The solve-panel items of
+  // the device runtime put the panels of the finished bottom levels back to zero behind them, so that the zero fill
+  // in front of the next factorisation covers the top levels only.)
+  for (int q = 0; q < ns; ++q) {
+    const int s = P.level_sn[q];
+    const int w = sn[s].w, r = P.sn_r[s];
+    P.sn_Loff[s] = Loff;
+    Loff += ((int64_t)r * w + 1) & ~1LL;
+  }
+  P.L_size = Loff;
   // relative indices: position of each below-row in the parent's front
   P.rel.resize(P.rel_ptr[ns]);
   for (int s = 0; s < ns; ++s) {

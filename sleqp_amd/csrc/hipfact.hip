@@ -6,6 +6,8 @@
 // usable GPU hipfact_create fails with HIPFACT_EDEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -15,6 +17,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hipfact.h"
@@ -193,6 +197,10 @@ struct PlanState {
   GraphList graphs;
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
+  // The solve-panel items of the dataflow launch leave the panels of the fronts BELOW the launch zeroed behind them
+  // (level-major arena: a prefix of l_prefix doubles), so the fill in front of the next factorisation skips them.
+  long long l_prefix = 0;  // 0: off for this plan
+  bool L_clean = false;    // the prefix is zero right now
   long long mini_x_off = 0;  // posted pivot blocks of the chain levels' small dataflow launches in d_xarena (doubles) ...
   size_t mini_x_bytes = 0;   // ... and how many bytes: back to the sentinel with every factorisation
   double ent_fused = 0, ent_split = 0, rows_fused = 0, rows_split = 0;  // L entries / row indices per kernel family
@@ -221,6 +229,10 @@ struct PlanState {
   PlanState& operator=(PlanState&&) = default;
 };
 
+#define VTABLE_SUPERSET_TYPES
+#include "vtable_superset.inc"
+#undef VTABLE_SUPERSET_TYPES
+
 struct hipfact_handle : PlanState {
   std::atomic<int> refcount{1};
   int device = 0;
@@ -242,6 +254,11 @@ struct hipfact_handle : PlanState {
   bool sp_folded = false;         // (result of the plan upload)
   bool solve_fused = true;        // one launch for the whole solve tree on the solve panels (when every front qualifies)
   bool assemble_superset = true;  // hipfact_assemble_kkt analyses a superset structure of J instead of K itself
+  bool superset_vtable = true;    // hipfact_set_matrix recognises the rows of an augmented K and reuses superset plans (vtable_superset.inc)
+  std::unique_ptr<VirtualJ> vj{new VirtualJ};
+  DevBuf d_kin, d_vsrc;           // the caller's values of K; value map into the virtual Jacobian
+  DevBuf d_retry_b;               // right-hand side kept across a retry on the exact row set
+  long vtable_retries = 0;
   bool jdev_valid = false;        // pattern of the Jacobian resident in d_jp / d_ji
   unsigned long long jdev_hash = 0;
   int jdev_n = 0, jdev_nnz = 0;
@@ -279,6 +296,7 @@ struct hipfact_handle : PlanState {
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_levels = 1 << 20;  // at most this many levels in the single-launch top-of-tree factorisation (tests)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
+  bool zero_behind = true;    // solve-panel items put the panels of the bottom levels back to zero (see l_prefix)
   int factor_top_post = 64;   // levels with at most this many fronts post the pivot block to polling panel workgroups
   int wide_min_rows = 256;    // fronts with at least this many update rows are solved by several workgroups (0: off; one workgroup streams a panel at ~50 GB/s)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
@@ -893,6 +911,12 @@ static int upload_plan(hipfact_handle* h) {
       h->ftop_level = lvl;
       h->ftop_count = (int)tf.size();
       h->ftop_lds = lds;
+      h->l_prefix = 0;
+      if (h->sp_folded && lvl > 0 && lvl < P.nlevels && h->zero_behind) {
+        bool whole = true;  // (a sliced front has several solve-panel items that read its pivot block: not handled)
+        for (int q2 = 0; q2 < nit && whole; ++q2) whole = P.sn_level[it_front[q2]] >= lvl || it_nsl[q2] == 1;
+        if (whole) h->l_prefix = P.sn_Loff[P.level_sn[P.level_ptr[lvl]]];
+      }
       for (int l = 0; l < lvl; ++l) {
         LevelInfo& lm = h->levels[l];
         if (lm.mini_cnt == 0) continue;
@@ -1194,18 +1218,28 @@ static inline unsigned long long* minmax_ptr(const hipfact_handle* h) {
   return reinterpret_cast<unsigned long long*>(h->d_info.as<char>() + INFO_WORDS * sizeof(int));
 }
 
+// this factorisation's solve-panel items zero the panels of the bottom levels behind them
+static bool zero_behind_now(const hipfact_handle* h) {
+  return h->l_prefix > 0 && h->sp_folded && h->fused_solve && !h->no_dataflow && h->debug_phases == 15 &&
+         h->ftop_level < h->plan.nlevels && !h->spanel_side;
+}
+
 // queue the numeric factorisation on the stream (values already in d_Kval)
 static int factor_enqueue(hipfact_handle* h) {
   const Plan& P = h->plan;
   hipStream_t st = h->stream;
   // the dependency counters of k_factor_top live behind the arena: one fill clears both
-  const size_t fill_bytes = (size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int);
+  const size_t fill_all = (size_t)P.L_size * sizeof(double) + (size_t)3 * P.nsuper * sizeof(int);
+  // the prefix the previous factorisation's solve-panel items zeroed behind them is skipped
+  const bool behind = zero_behind_now(h);
+  const size_t fill_skip = (behind && h->L_clean) ? (size_t)h->l_prefix * sizeof(double) : 0;
+  const size_t fill_bytes = fill_all - fill_skip;
   const bool fill_rides = P.saddle && P.n > 0 && P.m > 0;  // inside k_row_scale (with the info words)
   if (!fill_rides) {
     HCHECK(h, hipMemsetAsync(h->d_info.p, 0, INFO_BYTES, st));
     if (P.L_size > 0) {
       prof_begin(h, PC_MEMSET);
-      HCHECK(h, hipMemsetAsync(h->d_L.p, 0, fill_bytes, st));
+      HCHECK(h, hipMemsetAsync(h->d_L.as<char>() + fill_skip, 0, fill_bytes, st));
       prof_end(h);
     }
   }
@@ -1221,7 +1255,7 @@ static int factor_enqueue(hipfact_handle* h) {
       LAUNCH(PC_GATHER, k_row_scale, dim3(nbz + nblocks((long long)P.m * 16)), dim3(FB), 0, P.m,
              h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_src.as<int>(), h->d_Kval.as<double>(), vmap,
              h->equilibrate ? 1 : 0, h->d_dscale.as<double>(), h->d_Ar_val.as<double>(), h->d_Ksc.as<double>(), kprod,
-             nbz, h->d_L.as<double2>(), nz16, h->d_info.as<int>());
+             nbz, reinterpret_cast<double2*>(h->d_L.as<char>() + fill_skip), nz16, h->d_info.as<int>());
     }
   }
   if (nM > 0) {
@@ -1267,7 +1301,7 @@ static int factor_enqueue(hipfact_handle* h) {
       LAUNCH(PC_FACTOR_B, k_factor_top, dim3(li.mini_cnt), dim3(512), li.mini_lds,
              h->d_tfitems.as<TopFItem>() + li.mini_off, h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(),
              h->d_inv.as<int>(), h->d_rel.as<int>(), flm, flm + P.nsuper, flm + 2 * P.nsuper, h->d_xarena.as<double>(),
-             nullptr, nullptr, nullptr);
+             nullptr, nullptr, nullptr, 0);
       if (li.nD > 0)
         LAUNCH(PC_FACTOR_D, k_front_schur<false>, dim3(li.nD), dim3(FB), li.lds_schur, fit + li.itD, h->d_L.as<double>(),
                h->d_U.as<double>(), h->d_inv.as<int>(), h->d_rel.as<int>(), h->d_pullx.as<PullDesc>(), pull);
@@ -1315,8 +1349,9 @@ static int factor_enqueue(hipfact_handle* h) {
            h->d_L.as<double>(), h->d_U.as<double>(), h->d_info.as<int>(), h->d_inv.as<int>(), h->d_rel.as<int>(), fl,
            fl + P.nsuper, fl + 2 * P.nsuper, h->d_xarena.as<double>(),
            h->sp_folded ? h->d_sitems.as<SolveItem>() : nullptr, h->sp_folded ? h->d_SPf.as<double>() : nullptr,
-           h->sp_folded ? h->d_SPb.as<double>() : nullptr);
+           h->sp_folded ? h->d_SPb.as<double>() : nullptr, behind ? 1 : 0);
   }
+  h->L_clean = behind;  // (whatever else ran leaves the factor in the arena)
   if (h->fused_solve && !h->no_dataflow && !(h->sp_folded && lsplit < P.nlevels)) {
     if (sp_done > 0) HCHECK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     if (h->n_sitems > sp_done)
@@ -1335,7 +1370,10 @@ static DecideIn decide_in(hipfact_handle* h);
 
 static int factor_async(hipfact_handle* h) {
   flush_decide(h);  // a deferred verdict is judged against the pivot range of the factorisation it belongs to
-  const int rc = run_cached(h, 0, nullptr, nullptr, [&] { return factor_enqueue(h); });
+  // (two variants of the captured sequence: with the whole zero fill, and without the prefix the previous
+  // factorisation left clean)
+  const int rc = run_cached(h, 0, nullptr, nullptr, [&] { return factor_enqueue(h); },
+                            (zero_behind_now(h) && h->L_clean) ? 1 : 0);
   if (rc) return rc;
   h->num_factor++;
   h->factored = true;
@@ -1376,6 +1414,10 @@ static int check_info(hipfact_handle* h, const char* phase = "factorisation") {
   HCHECK(h, hipMemcpyAsync(h->h_info.p, h->d_info.p, INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   memcpy(h->info_host, h->h_info.p, INFO_WORDS * sizeof(int));
+  // The factorisation and the solve kernels count their timed-out waits in the same word.  After an asynchronous
+  // refactorisation (hipfact_refactor_device) the first reader may be a solve-phase caller: unless the factorisation
+  // has been looked at before, a timeout seen now may be its own and the factor cannot be trusted.
+  const bool factor_was_checked = h->factor_checked;
   h->factor_checked = true;
   if (h->fake_timeouts > 0) {
     --h->fake_timeouts;
@@ -1385,7 +1427,7 @@ static int check_info(hipfact_handle* h, const char* phase = "factorisation") {
   if (h->info_host[INFO_TIMEOUT] != 0) {
     snprintf(buf, sizeof buf, "dependency wait timed out inside the single-launch %s kernels (%d waits)", phase,
              h->info_host[INFO_TIMEOUT]);
-    const bool in_solve = !strcmp(phase, "solve");
+    const bool in_solve = !strcmp(phase, "solve") && factor_was_checked;
     if (!in_solve) h->factored = false;  // a solve does not touch the factor
     h->solved = false;
     const int rc = reset_dataflow_state(h);
@@ -1660,6 +1702,9 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
 }
 
 // Called by entry points that synchronise anyway: looks at the control block of the last solve,
+static bool vtable_can_retry(const hipfact_handle* h);
+static int vtable_retry_exact(hipfact_handle* h);
+
 // continues a refinement that is still running, and reports a solve that stalled far above the
 // tolerance (numerically singular working set) or a timed-out dataflow launch.
 static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
@@ -1683,6 +1728,16 @@ static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
   h->ctl_pending = false;
   h->last_ctl = c;
   if (continued) *continued = more > 0;
+  // A refinement that STALLS on a row-dictionary structure which carries rows outside the working set (unit pivots
+  // that take part in the ordering): for a nearly rank-deficient working set the quality of the statically pivoted
+  // factor as a preconditioner depends on the pivot order, and the order analysed for the rows of THIS K alone has
+  // been seen to converge where the superset's stalls (tests: graded family, nearly parallel rows).  Once per
+  // factorisation: the dictionary starts over from this K, and the solve is repeated on the new factor.
+  if (h->refine_adaptive && c.status == 1 && c.omega > 16.0 * c.tol && vtable_can_retry(h)) {
+    int rc = vtable_retry_exact(h);
+    if (rc) return rc;
+    return finish_solve(h, continued);
+  }
   if (c.iters > 0) h->num_refined++;
   h->num_passes += c.iters;
   // the next solves of this factorisation carry as many passes in their graph as this one needed
@@ -1813,6 +1868,44 @@ static int check_factor(hipfact_handle* h, bool could_fall_back) {
   return rc;
 }
 
+// roctx ranges around the boundary calls (set_matrix / solve / solution), switched on with HIPFACT_ROCTX=1: the
+// library is looked up at run time (no link dependency; rocprofv3 --marker-trace shows the ranges)
+struct RoctxRange {
+  typedef int (*push_fn)(const char*);
+  typedef int (*pop_fn)();
+  static pop_fn& pop_ptr() {
+    static pop_fn p = nullptr;
+    return p;
+  }
+  static push_fn push_ptr() {
+    static push_fn p = [] {
+      push_fn f = nullptr;
+      const char* e = getenv("HIPFACT_ROCTX");
+      if (e && atoi(e) != 0) {
+        void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+          f = reinterpret_cast<push_fn>(dlsym(lib, "roctxRangePushA"));
+          pop_ptr() = reinterpret_cast<pop_fn>(dlsym(lib, "roctxRangePop"));
+          if (!pop_ptr()) f = nullptr;
+        }
+      }
+      return f;
+    }();
+    return p;
+  }
+  bool on = false;
+  explicit RoctxRange(const char* name) {
+    if (push_fn f = push_ptr()) {
+      f(name);
+      on = true;
+    }
+  }
+  ~RoctxRange() {
+    if (on) pop_ptr()();
+  }
+};
+
 static int enter(hipfact_handle* h) {
   if (!h) return HIPFACT_EINVAL;
   hipError_t e = hipSetDevice(h->device);
@@ -1915,12 +2008,22 @@ int hipfact_free(hipfact_handle** handle) {
 
 const char* hipfact_last_error(const hipfact_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
+static int set_matrix_virtual(hipfact_handle* h, int N, const int* kp, const int* ki, const double* kx, bool* handled);
+
 int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* rowidx, const double* vals) {
+  RoctxRange range("hipfact_set_matrix");
   int rc = enter(h);
   if (rc) return rc;
   if (N < 0 || !colptr || (N > 0 && colptr[N] > 0 && (!rowidx || !vals))) {
     h->error = "hipfact_set_matrix: invalid arguments";
     return HIPFACT_EINVAL;
+  }
+  // An augmented matrix [I A_W^T; A_W 0] goes through the row dictionary (vtable_superset.inc): a working set made of
+  // rows seen before is a numeric refactorisation, whatever it does to the pattern of K
+  {
+    bool handled = false;
+    if ((rc = set_matrix_virtual(h, N, colptr, rowidx, vals, &handled))) return rc;
+    if (handled) return HIPFACT_OK;
   }
   // Steady state of an SQP run: the pattern is the active plan's.  All the host has to do then is compare 5 MB of
   // indices - which it can do WHILE the device works: the values and the factorisation are queued first on the
@@ -1982,6 +2085,7 @@ static int require_factor(hipfact_handle* h, const char* who) {
 }
 
 int hipfact_solve_dense(hipfact_handle* h, const double* rhs) {
+  RoctxRange range("hipfact_solve_dense");
   int rc = enter(h);
   if (rc) return rc;
   if ((rc = require_factor(h, "hipfact_solve_dense"))) return rc;
@@ -1996,6 +2100,7 @@ int hipfact_solve_dense(hipfact_handle* h, const double* rhs) {
 }
 
 int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices, const double* data) {
+  RoctxRange range("hipfact_solve_sparse");
   int rc = enter(h);
   if (rc) return rc;
   if ((rc = require_factor(h, "hipfact_solve_sparse"))) return rc;
@@ -2051,6 +2156,7 @@ int hipfact_solve_device(hipfact_handle* h, const double* d_rhs, double* d_sol) 
 }
 
 int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
+  RoctxRange range("hipfact_solution");
   int rc = enter(h);
   if (rc) return rc;
   if (!h->solved && h->N_ext > 0) {
@@ -2073,8 +2179,13 @@ int hipfact_solution(hipfact_handle* h, double* out, int begin, int end) {
   HCHECK(h, hipMemcpyAsync(dst, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   const bool could_fall_back = !h->no_dataflow;
   rc = check_info(h, "solve");  // synchronises
-  if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->factored && h->last_b && h->last_z) {
-    // the sweep timed out: the same solve once more through the per-level kernels
+  if (rc == HIPFACT_EINTERNAL && could_fall_back && h->no_dataflow && h->last_b && h->last_z) {
+    // the sweep timed out: the same solve once more through the per-level kernels - behind a fresh factorisation
+    // when the timed-out wait may have been the (unchecked) factorisation's own
+    if (!h->factored) {
+      if ((rc = factor_async(h))) return rc;
+      if ((rc = check_info(h))) return rc;
+    }
     if ((rc = solve_async(h, h->last_b, h->last_z))) return rc;
     if ((rc = finish_solve(h))) return rc;
     HCHECK(h, hipMemcpyAsync(dst, h->d_sol.as<double>() + begin, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2190,6 +2301,83 @@ static int build_superset_plan(hipfact_handle* h, int n, int m_total, const int*
   return HIPFACT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Superset path of the device assembly: finds (or analyses) a plan whose structure [I J_s^T; J_s 0] covers the working
+// set's constraint rows, then a numeric refactorisation.  The Jacobian (d_jp / d_ji / d_jx) and the working-set maps
+// (d_vi / d_ci) are on the device already; j_colptr / j_rowidx / cons_index are the host copies.
+static int superset_refactor(hipfact_handle* h, int n, int m_total, const int* j_colptr, const int* j_rowidx,
+                             const int* cons_index, int nav, int nac, int N, unsigned long long jhash, bool known) {
+  int rc;
+  const int jnnz = n > 0 ? j_colptr[n] : 0;
+  hipStream_t st = h->stream;
+  // ---- superset path: find a plan whose structure covers the working set's constraint rows
+  auto covers = [&](const PlanState& s) {
+    if (!(&s == static_cast<const PlanState*>(h) && known) &&
+        !(s.have_plan && s.from_jacobian && s.plan.n == n && (int)s.sidx.size() == m_total && s.key_hash == jhash &&
+          (int)s.Ji.size() == jnnz && memcmp(s.Jp.data(), j_colptr, (size_t)(n + 1) * sizeof(int)) == 0 &&
+          (jnnz == 0 || memcmp(s.Ji.data(), j_rowidx, (size_t)jnnz * sizeof(int)) == 0)))
+      return false;
+    for (int i = 0; i < m_total; ++i)
+      if (cons_index[i] >= 0 && s.sidx[i] < 0) return false;
+    // a structure far larger than the working set wastes the factorisation on unit rows
+    return 2LL * nac >= s.m_struct || s.m_struct - nac <= 256;
+  };
+  bool hit = covers(*h);
+  for (size_t i = 0; !hit && i < h->cache.size(); ++i)
+    if (covers(*h->cache[i])) {
+      swap_in(h, i);
+      hit = true;
+    }
+  h->use_stamp = ++h->use_clock;
+  if (hit) {
+    h->cache_hits++;
+  } else {
+    // new structure: every row of J when the working set holds most of them (rows then enter and leave
+    // without re-analysis), else the working set's rows plus those of a recent structure of this
+    // Jacobian when that stays close (working sets that oscillate)
+    std::vector<int> sidx((size_t)m_total, -1);
+    std::vector<char> cover((size_t)m_total, 0);
+    int ms = 0;
+    if (2LL * nac >= m_total) {
+      std::fill(cover.begin(), cover.end(), 1);
+    } else {
+      for (int i = 0; i < m_total; ++i) cover[i] = cons_index[i] >= 0;
+      const PlanState* prev = nullptr;
+      auto same_j = [&](const PlanState& s) {
+        return s.have_plan && s.from_jacobian && s.key_hash == jhash && (int)s.sidx.size() == m_total && s.plan.n == n;
+      };
+      if (same_j(*h)) prev = h;
+      for (size_t i = 0; !prev && i < h->cache.size(); ++i)
+        if (same_j(*h->cache[i])) prev = h->cache[i].get();
+      if (prev) {
+        int uni = 0;
+        for (int i = 0; i < m_total; ++i) uni += (cover[i] || prev->sidx[i] >= 0);
+        if (uni <= nac + nac / 4 + 64)
+          for (int i = 0; i < m_total; ++i) cover[i] = cover[i] || prev->sidx[i] >= 0;
+      }
+    }
+    for (int i = 0; i < m_total; ++i)
+      if (cover[i]) sidx[i] = ms++;
+    park_active(h);
+    h->key_hash = jhash;
+    h->use_stamp = h->use_clock;
+    if ((rc = build_superset_plan(h, n, m_total, j_colptr, j_rowidx, sidx, ms))) return rc;
+  }
+  h->maps_on = true;
+  h->N_ext = N;
+  h->n_bounds = nav;
+  const Plan& P = h->plan;
+  hipLaunchKernelGGL(k_struct_fill, dim3(nblocks(std::max(n, h->m_struct))), dim3(FB), 0, st, n, h->m_struct,
+                     h->d_jp.as<int>(), h->d_ji.as<int>(), h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(),
+                     h->d_sidx.as<int>(), h->d_srow.as<int>(), h->d_Kp.as<int>(), h->d_Kval.as<double>(),
+                     h->d_vmap.as<int>(), h->d_cmap.as<int>());
+  HCHECK(h, hipGetLastError());
+  (void)P;
+  return factor_and_check(h);
+}
+
+#include "vtable_superset.inc"
+
 int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_colptr, const int* j_rowidx,
                          const double* j_vals, const int* var_index, const int* cons_index, int working_set_size,
                          int* k_nnz, int* k_colptr, int* k_rowidx, double* k_vals) {
@@ -2201,6 +2389,7 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
   }
   const int jnnz = n > 0 ? j_colptr[n] : 0;
   const int N = n + working_set_size;
+  h->vj->dev_current = false;  // the device copies of the Jacobian and the maps are this call's from here on
   int nav = 0, nac = 0;
   for (int j = 0; j < n; ++j) nav += (var_index[j] >= 0);
   for (int i = 0; i < m_total; ++i) nac += (cons_index[i] >= 0);
@@ -2289,70 +2478,7 @@ int hipfact_assemble_kkt(hipfact_handle* h, int n, int m_total, const int* j_col
       HCHECK(h, hipMemcpyAsync(h->d_Kval.p, h->d_akx.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
     return factor_and_check(h);
   }
-  // ---- superset path: find a plan whose structure covers the working set's constraint rows
-  auto covers = [&](const PlanState& s) {
-    if (!(&s == static_cast<const PlanState*>(h) && known) &&
-        !(s.have_plan && s.from_jacobian && s.plan.n == n && (int)s.sidx.size() == m_total && s.key_hash == jhash &&
-          (int)s.Ji.size() == jnnz && memcmp(s.Jp.data(), j_colptr, (size_t)(n + 1) * sizeof(int)) == 0 &&
-          (jnnz == 0 || memcmp(s.Ji.data(), j_rowidx, (size_t)jnnz * sizeof(int)) == 0)))
-      return false;
-    for (int i = 0; i < m_total; ++i)
-      if (cons_index[i] >= 0 && s.sidx[i] < 0) return false;
-    // a structure far larger than the working set wastes the factorisation on unit rows
-    return 2LL * nac >= s.m_struct || s.m_struct - nac <= 256;
-  };
-  bool hit = covers(*h);
-  for (size_t i = 0; !hit && i < h->cache.size(); ++i)
-    if (covers(*h->cache[i])) {
-      swap_in(h, i);
-      hit = true;
-    }
-  h->use_stamp = ++h->use_clock;
-  if (hit) {
-    h->cache_hits++;
-  } else {
-    // new structure: every row of J when the working set holds most of them (rows then enter and leave
-    // without re-analysis), else the working set's rows plus those of a recent structure of this
-    // Jacobian when that stays close (working sets that oscillate)
-    std::vector<int> sidx((size_t)m_total, -1);
-    std::vector<char> cover((size_t)m_total, 0);
-    int ms = 0;
-    if (2LL * nac >= m_total) {
-      std::fill(cover.begin(), cover.end(), 1);
-    } else {
-      for (int i = 0; i < m_total; ++i) cover[i] = cons_index[i] >= 0;
-      const PlanState* prev = nullptr;
-      auto same_j = [&](const PlanState& s) {
-        return s.have_plan && s.from_jacobian && s.key_hash == jhash && (int)s.sidx.size() == m_total && s.plan.n == n;
-      };
-      if (same_j(*h)) prev = h;
-      for (size_t i = 0; !prev && i < h->cache.size(); ++i)
-        if (same_j(*h->cache[i])) prev = h->cache[i].get();
-      if (prev) {
-        int uni = 0;
-        for (int i = 0; i < m_total; ++i) uni += (cover[i] || prev->sidx[i] >= 0);
-        if (uni <= nac + nac / 4 + 64)
-          for (int i = 0; i < m_total; ++i) cover[i] = cover[i] || prev->sidx[i] >= 0;
-      }
-    }
-    for (int i = 0; i < m_total; ++i)
-      if (cover[i]) sidx[i] = ms++;
-    park_active(h);
-    h->key_hash = jhash;
-    h->use_stamp = h->use_clock;
-    if ((rc = build_superset_plan(h, n, m_total, j_colptr, j_rowidx, sidx, ms))) return rc;
-  }
-  h->maps_on = true;
-  h->N_ext = N;
-  h->n_bounds = nav;
-  const Plan& P = h->plan;
-  hipLaunchKernelGGL(k_struct_fill, dim3(nblocks(std::max(n, h->m_struct))), dim3(FB), 0, st, n, h->m_struct,
-                     h->d_jp.as<int>(), h->d_ji.as<int>(), h->d_jx.as<double>(), h->d_vi.as<int>(), h->d_ci.as<int>(),
-                     h->d_sidx.as<int>(), h->d_srow.as<int>(), h->d_Kp.as<int>(), h->d_Kval.as<double>(),
-                     h->d_vmap.as<int>(), h->d_cmap.as<int>());
-  HCHECK(h, hipGetLastError());
-  (void)P;
-  return factor_and_check(h);
+  return superset_refactor(h, n, m_total, j_colptr, j_rowidx, cons_index, nav, nac, N, jhash, known);
 }
 
 // ---------------------------------------------------------------------------
@@ -2361,7 +2487,7 @@ int hipfact_reduced_matrix(hipfact_handle* h, int* nnz_out, int* colptr, int* ro
   if (rc) return rc;
   const Plan& P = h->plan;
   if (!h->have_plan || !P.saddle || h->maps_on || !nnz_out) {
-    h->error = "hipfact_reduced_matrix: needs a saddle matrix set with hipfact_set_matrix";
+    h->error = "hipfact_reduced_matrix: needs a saddle matrix set with hipfact_set_matrix under set_option(\"superset_vtable\", 0) (the exact pattern of K, no working-set maps)";
     return HIPFACT_ESTATE;
   }
   const int m = P.m;
@@ -3033,6 +3159,10 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     invalidate_plans(h);
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "superset_vtable")) {  // 0: hipfact_set_matrix analyses the pattern of K itself (exact-pattern plan cache only)
+    h->superset_vtable = value != 0.0;
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "assemble_superset")) {
     h->assemble_superset = value != 0.0;
     return HIPFACT_OK;
@@ -3130,7 +3260,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor) INFO("vtable_rows", h->vj->rows()) INFO("vtable_retries", h->vtable_retries) INFO("superset_vtable", h->superset_vtable)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

@@ -2659,7 +2659,7 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
                                                    int* __restrict__ bdone, int* __restrict__ cdone,
                                                    int* __restrict__ ddone, double* __restrict__ xarena,
                                                    const SolveItem* __restrict__ sitems, double* __restrict__ SPf,
-                                                   double* __restrict__ SPb) {
+                                                   double* __restrict__ SPb, int zero_behind) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TopFItem& T = items[blockIdx.x];
   const FrontItem& S = T.it;
@@ -2686,6 +2686,15 @@ __global__ __launch_bounds__(512) void k_factor_top(const TopFItem* __restrict__
     }
     TRW(1);
     dev_build_solve_panel(sitems[S.part], L, SPf, SPb, lds);
+    // A front BELOW this launch: nobody reads its panel any more (its parent took the update matrix, the solves
+    // run on the solve panels) - it goes back to zero here, in the shadow of the latency-bound top of the tree,
+    // instead of in the zero fill in front of the next factorisation.
+    if (zero_behind && !T.nwait) {
+      __syncthreads();
+      double2* __restrict__ pz = reinterpret_cast<double2*>(L + S.Loff);
+      const long long n2 = ((long long)S.r * S.w + 1) >> 1;
+      for (long long e = threadIdx.x; e < n2; e += blockDim.x) pz[e] = double2{0.0, 0.0};
+    }
 #ifdef HIPFACT_TRACE
     __syncthreads();
 #endif

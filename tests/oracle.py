@@ -195,3 +195,19 @@ class OracleLdl:
                 self._f = None
         except Exception:
             pass
+
+
+def reduced_aug_jac(n, m_total, jp, ji, jx, var_index, cons_index, W):
+    """The matrix reduced_aug_jac.c hands to a PSD-flagged backend (compute_matrix_lower, :323-377): lower CSC of
+    A_W A_W^T with EVERY entry below the diagonal stored (the reference's inner product reports nonzero
+    unconditionally).  Returns (cols, rows, data)."""
+    jp, ji = np.ascontiguousarray(jp, dtype=np.int32), np.ascontiguousarray(ji, dtype=np.int32)
+    jx = np.ascontiguousarray(jx, dtype=np.float64)
+    vi, ci = np.ascontiguousarray(var_index, dtype=np.int32), np.ascontiguousarray(cons_index, dtype=np.int32)
+    cap = max(W * (W + 1) // 2, 1)
+    cols, rows, data = np.zeros(W + 1, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.float64)
+    f = lib().oracle_reduced_aug_jac
+    f.restype = C.c_int
+    nnz = f(C.c_int(n), C.c_int(m_total), _p(jp), _p(ji), _p(jx), _p(vi), _p(ci), C.c_int(W), _p(cols), _p(rows), _p(data))
+    assert nnz == W * (W + 1) // 2
+    return cols, rows[:nnz], data[:nnz]

@@ -489,6 +489,114 @@ def test_working_set_changes_reuse_the_superset_plan(fact):
     assert rel_err(p1, p0) <= 1e-12
 
 
+def test_vtable_set_matrix_reuses_the_superset_plan(fact):
+    """The PLAIN SleqpFact boundary (standard_aug_jac.c assembles K on the host, sleqp_fact_set_matrix gets nothing
+    but K): the rows of A_W are recognised by content, so a working set made of rows seen before - whatever it does
+    to the pattern of K - is a numeric refactorisation; a row never seen before extends the dictionary and costs one
+    analysis.  All three AugJac solves against the oracle for every working set."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 900, 400
+    J = synth.banded_jacobian(n, m, 10, 80, 31)
+    rng = np.random.default_rng(21)
+    aug = StandardAugJac(n, fact, device_assembly=False)  # fill_aug_jac on the host, fact.set_matrix(K)
+    g = rng.standard_normal(n)
+
+    def check(vi, ci, W):
+        aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        assert np.array_equal(aug.K.cols, kc) and np.array_equal(aug.K.rows, kr) and np.array_equal(aug.K.data, kd)
+        ref = oracle.OracleFact(N, kc, kr, kd)
+        idx, val = ref.project_nullspace(n, np.arange(n), g)
+        assert rel_err(aug.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+        idx, val = ref.solve_lsq(n, np.arange(n), g)
+        assert rel_err(aug.solve_lsq(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(W, idx, val)) <= REL_TOL
+        if W > 0:
+            c = rng.standard_normal(W)
+            idx, val = ref.solve_min_norm(n, np.arange(W), c)
+            assert rel_err(aug.solve_min_norm(SleqpVec.from_raw(c)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+        b = rng.standard_normal(N)
+        ref.solve_dense(b)
+        fact.solve(b)
+        assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL
+
+    vi, ci, W = _ws(n, m, rng, 1.0, 0.05)  # every row of J once: the dictionary is complete
+    check(vi, ci, W)
+    assert fact.info("analyses") == 1 and fact.info("maps_on") == 1 and fact.info("vtable_rows") == m
+    for it in range(6):  # rows and bounds enter and leave: same plan, numeric refactorisation only
+        vi, ci, W = _ws(n, m, rng, [0.99, 0.95, 0.8, 0.6, 0.97, 1.0][it], [0.0, 0.1, 0.02, 0.3, 0.05, 0.0][it])
+        check(vi, ci, W)
+        assert fact.info("analyses") == 1, it
+    same = (vi, ci, W)
+    check(*same)  # the very same K again: recognised by comparison, nothing rebuilt
+    assert fact.info("analyses") == 1
+    # changed VALUES on an unchanged pattern
+    J2 = J.copy()
+    J2.data = J2.data * (1.0 + 0.1 * rng.standard_normal(J2.nnz))
+    Jkeep, J = J, J2
+    check(*same)
+    assert fact.info("analyses") == 1
+    J = Jkeep
+    # a much smaller working set gets a structure of its own; both stay cached
+    small = _ws(n, m, rng, 0.2, 0.05)
+    check(*small)
+    assert fact.info("analyses") == 2 and fact.info("m_struct") < m // 2
+    check(*same)
+    check(*small)
+    assert fact.info("analyses") == 2
+    # bounds only; the empty working set takes the plain path (no rows to recognise)
+    check(*_ws(n, m, rng, 0.0, 0.2))
+    # rows never seen before: the dictionary grows, one analysis, then reuse again
+    fact2 = type(fact)()
+    aug2 = StandardAugJac(n, fact2, device_assembly=False)
+    first = _ws(n, m, rng, 0.5, 0.0)
+
+    def check2(vi, ci, W):
+        aug2.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        ref = oracle.OracleFact(N, kc, kr, kd)
+        idx, val = ref.project_nullspace(n, np.arange(n), g)
+        assert rel_err(aug2.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+
+    check2(*first)
+    assert fact2.info("analyses") == 1
+    vi, ci, W = first
+    ci2 = ci.copy()
+    out = np.flatnonzero(ci2 < 0)[:40]  # forty rows that have never been active enter
+    act = np.sort(np.concatenate([np.flatnonzero(ci2 >= 0), out]))
+    ci2[:] = -1
+    ci2[act] = np.arange(act.size)
+    check2(vi, ci2, int(act.size))
+    assert fact2.info("analyses") == 2 and fact2.info("vtable_rows") == act.size
+    check2(*first)  # back to a subset of the dictionary
+    ci3 = ci2.copy()
+    drop = act[::7]
+    keep = np.setdiff1d(act, drop)
+    ci3[:] = -1
+    ci3[keep] = np.arange(keep.size)
+    check2(vi, ci3, int(keep.size))
+    assert fact2.info("analyses") == 2
+    # identical rows (twins) are told apart by their order of appearance
+    Jt = sp.vstack([J.tocsr()[:50], J.tocsr()[:50]]).tocsc()
+    fact3 = type(fact)()
+    aug3 = StandardAugJac(n, fact3, device_assembly=False)
+    vi0 = np.full(n, -1, dtype=np.int32)
+    ci_t = np.full(100, -1, dtype=np.int32)
+    rows_t = np.r_[np.arange(0, 50, 2), 50 + np.arange(1, 50, 2)]  # no two twins together: full row rank
+    ci_t[rows_t] = np.arange(rows_t.size)
+    aug3.set_iterate(SleqpMat.from_scipy(Jt), vi0, ci_t)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, 100, Jt.indptr, Jt.indices, Jt.data, vi0, ci_t)
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    idx, val = ref.project_nullspace(n, np.arange(n), g)
+    assert rel_err(aug3.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+    # the option switches the exact-pattern path back on
+    fact3.set_option("superset_vtable", 0)
+    aug3.set_iterate(SleqpMat.from_scipy(Jt), vi0, ci_t)
+    assert fact3.info("maps_on") == 0
+    assert rel_err(aug3.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+
+
 def test_pattern_lru_for_set_matrix(fact):
     """Unmodified standard_aug_jac.c in front of the backend: K's pattern changes with the working
     set; patterns seen before are served from the plan LRU (no analysis, no upload, no graph capture)."""
@@ -497,6 +605,7 @@ def test_pattern_lru_for_set_matrix(fact):
     n, m = 500, 220
     J = synth.banded_jacobian(n, m, 8, 60, 4)
     rng = np.random.default_rng(3)
+    fact.set_option("superset_vtable", 0)  # the exact-pattern plan cache (the row dictionary has a test of its own)
     sets = [_ws(n, m, rng, f, bf) for f, bf in ((1.0, 0.0), (0.9, 0.05), (0.5, 0.0))]
     mats = [oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci) for vi, ci, _ in sets]
     for rnd in range(3):
@@ -513,14 +622,20 @@ def test_pattern_lru_for_set_matrix(fact):
 
 def test_reduced_matrix_is_the_sparse_product(fact):
     """S = A_W A_W^T from the device (product lists = symbolic SpGEMM, one fixed-order sum per
-    structural entry) against scipy, in working-set row order, sparse where reduced_aug_jac.c:323-377 is dense."""
+    structural entry) against the matrix reduced_aug_jac.c:323-377 builds (restated in the oracle) and against
+    scipy, in working-set row order - sparse where the reference stores the whole lower triangle."""
     from sleqp_amd.sparse import SleqpMat
 
+    fact.set_option("superset_vtable", 0)  # the exact pattern of K: no working-set maps between S and the caller
     for n, m, kind, frac in [(7, 3, "u", 0.3), (300, 150, "b", 0.1), (2000, 900, "u", 0.05)]:
         J, vi, ci, W = _problem(n, m, kind, frac, 5)
         N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
         fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
         S = fact.reduced_matrix()
+        if W <= 1200:
+            rc_, rr_, rd_ = oracle.reduced_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci, W)
+            Sref = sp.csc_matrix((rd_, rr_, rc_), shape=(W, W))
+            assert abs(S - Sref).max() <= 1e-13 * max(1.0, abs(Sref).max())
         K = sp.csc_matrix((kd, kr, kc), shape=(N, N))
         A = K[n:, :n].tocsr()
         want = sp.tril(A @ A.T, format="csc")

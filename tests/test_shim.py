@@ -176,6 +176,142 @@ def test_aug_jac_shim_against_golden(shim, c):
 HESS_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
+def _push_lower(shim, N, kc, kr, kd):
+    K = C.c_void_p()
+    assert shim.sleqp_mat_create(C.byref(K), N, N, max(len(kd), 1)) == 0
+    for j in range(N):
+        assert shim.sleqp_mat_push_col(K, j) == 0
+        for e in range(kc[j], kc[j + 1]):
+            assert shim.sleqp_mat_push(K, int(kr[e]), j, C.c_double(float(kd[e]))) == 0
+    return K
+
+
+def _fact_solve(shim, fact, rhs_dense, begin, end):
+    """sleqp_fact_solve + sleqp_fact_solution through the vtable, dense in / dense out."""
+    N = len(rhs_dense)
+    nz = np.flatnonzero(rhs_dense)
+    rhs = _vec(shim, N, nz, rhs_dense[nz])
+    assert shim.sleqp_fact_solve(fact, rhs) == 0, shim.sleqp_error_msg()
+    sol = C.POINTER(SleqpVecC)()
+    assert shim.sleqp_vec_create_empty(C.byref(sol), end - begin) == 0
+    assert shim.sleqp_fact_solution(fact, sol, begin, end, C.c_double(ZERO_EPS)) == 0, shim.sleqp_error_msg()
+    out = _dense(sol)
+    shim.sleqp_vec_free(C.byref(rhs))
+    shim.sleqp_vec_free(C.byref(sol))
+    return out
+
+
+@pytest.mark.gpu
+def test_fact_shim_changing_working_sets_cost_one_analysis(shim, hipfact_lib):
+    """-DSLEQP_FACT=HIPFACT alone, i.e. the unmodified standard_aug_jac.c in front of the backend: successive
+    fill_aug_jac outputs (restated by the oracle) go through sleqp_fact_set_matrix of the C shim; the three AugJac
+    solves (standard_aug_jac.c:306-435, restated here on sleqp_fact_solve / _solution) are checked against the
+    oracle for every working set, and the whole run costs ONE symbolic analysis.  The shim reports what each call
+    did at debug level (sleqp_log_debug)."""
+    import oracle
+    from sleqp_amd import synth
+
+    n, m = 700, 320
+    J = synth.banded_jacobian(n, m, 10, 70, 8)
+    rng = np.random.default_rng(4)
+    settings, fact = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    shim.sleqp_log_set_level(4)  # SLEQP_LOG_DEBUG
+    shim.sleqp_mini_log_drain.restype = C.c_char_p
+    shim.sleqp_mini_log_drain()
+    assert shim.sleqp_fact_create_default(C.byref(fact), settings) == 0, shim.sleqp_error_msg()
+    shim.sleqp_fact_hipfact_last_handle.restype = C.c_void_p
+    handle = C.c_void_p(shim.sleqp_fact_hipfact_last_handle())
+    hipfact_lib.hipfact_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+
+    def info(name):
+        v = C.c_double()
+        assert hipfact_lib.hipfact_get_info(handle, name.encode(), C.byref(v)) == 0
+        return v.value
+
+    g = rng.standard_normal(n)
+    logs = []
+    for it, (rf, bf) in enumerate([(1.0, 0.04), (0.97, 0.0), (0.9, 0.1), (0.99, 0.02), (0.8, 0.0), (0.95, 0.05)]):
+        vi = np.full(n, -1, dtype=np.int32)
+        av = np.sort(rng.choice(n, int(round(bf * n)), replace=False))
+        vi[av] = np.arange(av.size)
+        ci = np.full(m, -1, dtype=np.int32)
+        ac = np.sort(rng.choice(m, int(round(rf * m)), replace=False))
+        ci[ac] = av.size + np.arange(ac.size)
+        W = int(av.size + ac.size)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        K = _push_lower(shim, N, kc, kr, kd)
+        assert shim.sleqp_fact_set_matrix(fact, K) == 0, shim.sleqp_error_msg()
+        logs.append(shim.sleqp_mini_log_drain().decode())
+        ref = oracle.OracleFact(N, kc, kr, kd)
+        rhs = np.r_[g, np.zeros(W)]
+        idx, val = ref.project_nullspace(n, np.arange(n), g)  # rhs [g; 0] -> solution(0, n)
+        assert rel_err(_fact_solve(shim, fact, rhs, 0, n), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+        idx, val = ref.solve_lsq(n, np.arange(n), g)          # rhs [g; 0] -> solution(n, N)
+        assert rel_err(_fact_solve(shim, fact, rhs, n, N), oracle.vec_to_raw(W, idx, val)) <= REL_TOL
+        cvec = rng.standard_normal(W)
+        idx, val = ref.solve_min_norm(n, np.arange(W), cvec)  # rhs [0; c] -> solution(0, n)
+        assert rel_err(_fact_solve(shim, fact, np.r_[np.zeros(n), cvec], 0, n), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+        assert info("analyses") == 1, it
+        shim.sleqp_mat_release(C.byref(K))
+    assert "symbolic analysis #1" in logs[0] and "working-set superset" in logs[0]
+    assert all("symbolic analysis" not in t for t in logs[1:])
+    shim.sleqp_log_set_level(3)
+    assert shim.sleqp_fact_release(C.byref(fact)) == 0
+    shim.sleqp_settings_release(C.byref(settings))
+
+
+@pytest.mark.gpu
+def test_psd_fact_shim_behind_the_reduced_aug_jac(shim, hipfact_lib):
+    """sleqp_fact_hipfact_psd_create declares PSD | LOWER (pattern fact_cholmod.c:231-262): create_aug_jac
+    (trial_point.c:94-101) then puts the reduced AugJac in front of it, whose matrix is the lower triangle of
+    A_W A_W^T as reduced_aug_jac.c:323-377 builds it (restated in the oracle: every entry below the diagonal is
+    stored).  set_matrix / solve / solution through the vtable against a dense solve; the three reduced AugJac
+    solves (reduced_aug_jac.c:440-640) composed on the host like there, against the oracle's KKT solves."""
+    import oracle
+    import scipy.sparse as sp
+    from sleqp_amd import synth
+
+    n, m = 260, 120
+    J = synth.banded_jacobian(n, m, 8, 50, 2)
+    rng = np.random.default_rng(6)
+    vi = np.full(n, -1, dtype=np.int32)
+    av = np.sort(rng.choice(n, 9, replace=False))
+    vi[av] = np.arange(av.size)
+    ci = np.full(m, -1, dtype=np.int32)
+    ac = np.sort(rng.choice(m, 100, replace=False))
+    ci[ac] = av.size + np.arange(ac.size)
+    W = int(av.size + ac.size)
+    sc, sr, sd = oracle.reduced_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci, W)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    A = sp.csc_matrix((kd, kr, kc), shape=(N, N))[n:, :n].toarray()
+    S = sp.csc_matrix((sd, sr, sc), shape=(W, W)).toarray()
+    assert np.abs(S - np.tril(A @ A.T)).max() <= 1e-12 * np.abs(S).max()  # the restatement itself
+    settings, fact = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    assert shim.sleqp_fact_hipfact_psd_create(C.byref(fact), settings) == 0, shim.sleqp_error_msg()
+    assert shim.sleqp_fact_flags(fact) == 3  # SLEQP_FACT_FLAGS_PSD | SLEQP_FACT_FLAGS_LOWER
+    Sm = _push_lower(shim, W, sc, sr, sd)
+    assert shim.sleqp_fact_set_matrix(fact, Sm) == 0, shim.sleqp_error_msg()
+    Sfull = S + np.tril(S, -1).T
+    b = rng.standard_normal(W)
+    assert rel_err(_fact_solve(shim, fact, b, 0, W), np.linalg.solve(Sfull, b)) <= REL_TOL
+    # the reduced AugJac solves on top of it, against the oracle's solves with K
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    g = rng.standard_normal(n)
+    y = _fact_solve(shim, fact, A @ g, 0, W)                     # lsq: (A A^T) y = A g
+    idx, val = ref.solve_lsq(n, np.arange(n), g)
+    assert rel_err(y, oracle.vec_to_raw(W, idx, val)) <= REL_TOL
+    idx, val = ref.project_nullspace(n, np.arange(n), g)        # projection: g - A^T y
+    assert rel_err(g - A.T @ y, oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+    cvec = rng.standard_normal(W)
+    idx, val = ref.solve_min_norm(n, np.arange(W), cvec)        # min norm: A^T (A A^T)^-1 c
+    assert rel_err(A.T @ _fact_solve(shim, fact, cvec, 0, W), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
+    shim.sleqp_mat_release(C.byref(Sm))
+    assert shim.sleqp_fact_release(C.byref(fact)) == 0
+    shim.sleqp_settings_release(C.byref(settings))
+
+
 def _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver, stat_tol=1e-6, max_iter=100, linear=False):
     class Case:  # what _fill_jac reads
         pass
