@@ -1,10 +1,15 @@
-import sys, os, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
-from sleqp_amd import synth, _lib
+"""Phase timing of the host analysis (HIPFACT_TIMING=1) for a bench workload; no GPU needed."""
+import os, sys, time
+os.environ["HIPFACT_TIMING"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from plan_emul import Plan
-lib = _lib.load()
-J = synth.banded_jacobian(100000, 50000, 20, 200, 0)
-N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
-for i in range(2):
-    t = time.time(); P = Plan(lib, N, cp, ri, vx); dt = time.time() - t
-    print(f"total {dt:.3f}s  (plan: order {P.t_order:.3f} symbolic {P.t_symbolic:.3f} total {P.t_total:.3f})")
+from sleqp_amd import _lib, synth
+n, m = 100000, 50000
+J = synth.banded_jacobian(n, m, 20, 200, 0)
+vi, ci, _ = synth.working_set_all_rows(n, m)
+N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+for _ in range(3):
+    t0 = time.perf_counter()
+    p = Plan(_lib.load(), N, cp, ri)
+    print("plan build (incl. export) %.1f ms" % (1e3 * (time.perf_counter() - t0)), file=sys.stderr)

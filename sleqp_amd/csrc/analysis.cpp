@@ -136,6 +136,73 @@ struct RawSuper {
 
 // Supernodal symbolic factorisation for a postordered matrix.  Fills the
 // supernode partition with row structures and the per-column counts.
+//
+// One column of the symbolic factorisation (shared by the serial sweep and the per-subtree workers): `sn` is the
+// list the column's supernode is appended to / extended in, `mark` a scratch array of m ints private to the caller.
+struct SymbolicCtx {
+  const Graph& g;
+  const std::vector<int>& perm;
+  const std::vector<int>& iperm;
+  const std::vector<int>& parent;
+  const std::vector<int>& head;
+  const std::vector<int>& next;
+  std::vector<int>& sn_of;      // column -> index of its supernode IN THE LIST IT WAS APPENDED TO
+  std::vector<const std::vector<RawSuper>*>& list_of;  // column -> that list
+  std::vector<int>& colcount;
+};
+
+inline void symbolic_column(const SymbolicCtx& C, int j, std::vector<RawSuper>& sn, std::vector<int>& mark,
+                            std::vector<int>& extras) {
+  const bool chain = (j > 0 && C.parent[j - 1] == j) && !sn.empty() && sn.back().c0 + sn.back().w == j;
+  const int stamp = chain ? sn.back().c0 : j;  // rows of the open supernode are marked with its c0
+  extras.clear();
+  auto visit = [&](int i) {
+    if (i > j && mark[i] != stamp) {
+      mark[i] = stamp;
+      extras.push_back(i);
+    }
+  };
+  const int v = C.perm[j];
+  for (int64_t q = C.g.ptr[v]; q < C.g.ptr[v + 1]; ++q) visit(C.iperm[C.g.adj[q]]);
+  for (int c = C.head[j]; c != -1; c = C.next[c]) {
+    if (chain && c == j - 1) continue;
+    const RawSuper& cs = (*C.list_of[c])[(size_t)C.sn_of[c]];
+    // c is the last column of its supernode: struct(c) = below rows
+    for (size_t t = cs.w; t < cs.rows.size(); ++t) visit(cs.rows[t]);
+  }
+  if (chain && extras.empty()) {
+    RawSuper& s = sn.back();
+    if (C.next[C.head[j]] != -1) s.joins.push_back(j - s.c0);  // more children than the chain predecessor
+    s.w += 1;
+    C.sn_of[j] = (int)sn.size() - 1;
+    C.list_of[j] = &sn;
+    C.colcount[j] = (int)s.rows.size() - (j - s.c0);
+    return;
+  }
+  RawSuper ns;
+  ns.c0 = j;
+  ns.w = 1;
+  if (chain) {
+    // inherit the tail of the open supernode (it was marked with the old
+    // stamp; re-mark with the new one together with the extras)
+    const RawSuper& s = sn.back();
+    for (size_t t = (size_t)(j - s.c0) + 1; t < s.rows.size(); ++t) extras.push_back(s.rows[t]);
+  }
+  std::sort(extras.begin(), extras.end());
+  ns.rows.reserve(extras.size() + 1);
+  ns.rows.push_back(j);
+  ns.rows.insert(ns.rows.end(), extras.begin(), extras.end());
+  for (int i : ns.rows) mark[i] = j;  // stamp of the new open supernode = its c0
+  C.colcount[j] = (int)ns.rows.size();
+  C.sn_of[j] = (int)sn.size();
+  C.list_of[j] = &sn;
+  sn.push_back(std::move(ns));
+}
+
+// The columns of a subtree are a contiguous range of a postordered matrix and touch nothing outside it but the row
+// indices of their ancestors: disjoint subtrees are processed by threads of their own (private mark arrays, private
+// supernode lists), then one serial sweep in column order splices the lists and handles the columns above them
+// (the separators at the top of a nested-dissection ordering: few, but with long row lists).
 void symbolic(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm,
               const std::vector<int>& parent, std::vector<RawSuper>& sn, std::vector<int>& colcount) {
   const int m = g.n;
@@ -147,57 +214,66 @@ void symbolic(const Graph& g, const std::vector<int>& perm, const std::vector<in
       next[k] = head[parent[k]];
       head[parent[k]] = k;
     }
-  std::vector<int> mark(m, -1), sn_of(m, -1);
-  std::vector<int> extras;
-  for (int j = 0; j < m; ++j) {
-    const bool chain = (j > 0 && parent[j - 1] == j);
-    int stamp;
-    if (chain) {
-      stamp = sn.back().c0;  // rows of the open supernode are marked with its c0
-    } else {
-      stamp = j;
-    }
-    extras.clear();
-    auto visit = [&](int i) {
-      if (i > j && mark[i] != stamp) {
-        mark[i] = stamp;
-        extras.push_back(i);
+  std::vector<int> sn_of(m, -1);
+  std::vector<const std::vector<RawSuper>*> list_of((size_t)m, nullptr);
+  const SymbolicCtx C{g, perm, iperm, parent, head, next, sn_of, list_of, colcount};
+  // subtree sizes (children precede parents) and the maximal subtrees of at most `cap` columns
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int nt = std::min(hw, 16);
+  std::vector<int> first;  // first column of each chosen subtree; root[t] its last
+  std::vector<int> root;
+  if (nt > 1 && m >= 8192) {
+    std::vector<int> size(m, 1);
+    for (int k = 0; k < m; ++k)
+      if (parent[k] != -1) size[parent[k]] += size[k];
+    const int cap = std::max(256, m / (4 * nt));
+    for (int k = 0; k < m; ++k) {
+      const bool fits = size[k] <= cap;
+      const bool parent_fits = parent[k] != -1 && size[parent[k]] <= cap;
+      if (fits && !parent_fits && size[k] >= 64) {
+        first.push_back(k - size[k] + 1);
+        root.push_back(k);
       }
-    };
-    const int v = perm[j];
-    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) visit(iperm[g.adj[q]]);
-    for (int c = head[j]; c != -1; c = next[c]) {
-      if (chain && c == j - 1) continue;
-      const RawSuper& cs = sn[sn_of[c]];
-      // c is the last column of its supernode: struct(c) = below rows
-      for (size_t t = cs.w; t < cs.rows.size(); ++t) visit(cs.rows[t]);
     }
-    if (chain && extras.empty()) {
-      RawSuper& s = sn.back();
-      if (next[head[j]] != -1) s.joins.push_back(j - s.c0);  // more children than the chain predecessor
-      s.w += 1;
-      sn_of[j] = (int)sn.size() - 1;
-      colcount[j] = (int)s.rows.size() - (j - s.c0);
+  }
+  const int nsub = (int)first.size();
+  std::vector<std::vector<RawSuper>> lists((size_t)nsub);
+  if (nsub > 0) {
+    std::atomic<int> nextsub{0};
+    auto worker = [&]() {
+      std::vector<int> mark(m, -1), extras;
+      for (int t = nextsub++; t < nsub; t = nextsub++)
+        for (int j = first[(size_t)t]; j <= root[(size_t)t]; ++j) symbolic_column(C, j, lists[(size_t)t], mark, extras);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < std::min(nt, nsub); ++t) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
+  }
+  // serial sweep: splice the lists in column order, process what lies between and above them
+  std::vector<int> mark(m, -1), extras;
+  int t = 0;
+  for (int j = 0; j < m;) {
+    if (t < nsub && first[(size_t)t] == j) {
+      const int base = (int)sn.size();
+      for (RawSuper& s : lists[(size_t)t]) sn.push_back(std::move(s));
+      for (int c = j; c <= root[(size_t)t]; ++c) {
+        sn_of[c] += base;
+        list_of[c] = &sn;
+      }
+      // the rows of the (possibly still open) last supernode carry its stamp in the worker's mark array, not in this
+      // one: re-mark them, a chain column right behind the subtree relies on it
+      {
+        const RawSuper& s = sn.back();
+        for (int i : s.rows) mark[i] = s.c0;
+      }
+      j = root[(size_t)t] + 1;
+      ++t;
       continue;
     }
-    RawSuper ns;
-    ns.c0 = j;
-    ns.w = 1;
-    if (chain) {
-      // inherit the tail of the open supernode (it was marked with the old
-      // stamp; re-mark with the new one together with the extras)
-      const RawSuper& s = sn.back();
-      for (size_t t = (size_t)(j - s.c0) + 1; t < s.rows.size(); ++t) extras.push_back(s.rows[t]);
-    }
-    std::sort(extras.begin(), extras.end());
-    ns.rows.reserve(extras.size() + 1);
-    ns.rows.push_back(j);
-    ns.rows.insert(ns.rows.end(), extras.begin(), extras.end());
-    for (int i : ns.rows) mark[i] = j;  // stamp of the new open supernode = its c0
-    colcount[j] = (int)ns.rows.size();
-    sn_of[j] = (int)sn.size();
-    sn.push_back(std::move(ns));
+    symbolic_column(C, j, sn, mark, extras);
+    ++j;
   }
+  // (sn.reserve() is not used above: list_of holds pointers to the vector OBJECT, which never moves)
 }
 
 inline int64_t trapezoid(int64_t w, int64_t r) { return w * r - w * (w - 1) / 2; }
@@ -581,7 +657,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   std::vector<int> parent, post, colcount;
   std::vector<RawSuper> sn;
   for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 0) etree(g, perm, iperm, parent);
+    if (pass == 0) {
+      etree(g, perm, iperm, parent);
+      tick("  etree");
+    }
     postorder(parent, pass == 0 ? nullptr : &colcount, post);
     std::vector<int> perm2(m), inv(m), parent2(m);
     for (int k = 0; k < m; ++k) {
@@ -592,7 +671,9 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     perm.swap(perm2);
     parent.swap(parent2);
     for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
+    tick("  postorder + relabel");
     symbolic(g, perm, iperm, parent, sn, colcount);
+    tick("  symbolic");
   }
   P.nnzL_true = 0;
   P.flops = 0;

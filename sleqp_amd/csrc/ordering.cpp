@@ -659,7 +659,9 @@ struct NDState {
     }
     int ecc = -1;
     bool fresh = false;  // order / lev_ptr belong to the current root
-    for (int it = 0; it < 6; ++it) {  // (usually converges after two or three sweeps)
+    // (usually converges after two or three sweeps; every sweep of a large subgraph is serial time in front of the
+    // parallel part of the dissection)
+    for (int it = 0; it < (k > 16384 ? 3 : 6); ++it) {
       bfs(root, id, order, lev_ptr);
       fresh = true;
       if (it == 0 && (int)order.size() < k) {
