@@ -860,6 +860,88 @@ fail:
   return NULL;
 }
 
+/* Numeric-only refactorisation: new values of the SAME pattern, permutation, elimination tree and column pointers
+ * of F reused (what a CPU backend that kept its symbolic phase would pay per SQP iteration; the reference's backends
+ * do not, fact_ma57.c:529-625 - reported next to the symbolic-inclusive figure as `numeric_only`).  Returns 0, or -1
+ * on a zero pivot. */
+int oracle_ldl_refactor(OracleLdl* F, const int* Kp, const int* Ki, const double* Kx)
+{
+  const int n = F->n;
+  if (!F->Li || !F->Lx)
+    return -1;
+  int* Lnz     = (int*)calloc((size_t)n + 1, sizeof(int));
+  int* Flag    = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  int* Pattern = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  int* fill    = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  int rc       = 0;
+  if (!Lnz || !Flag || !Pattern || !fill)
+  {
+    rc = -1;
+    goto done;
+  }
+  memcpy(fill, F->Up, sizeof(int) * (size_t)n);
+  for (int c = 0; c < n; ++c)
+    for (int e = Kp[c]; e < Kp[c + 1]; ++e)
+    {
+      const int a = F->Pinv[Ki[e]], b = F->Pinv[c];
+      const int col = a > b ? a : b;
+      F->Ux[fill[col]++] = Kx[e];
+    }
+  {
+    double* Y = F->work;
+    for (int k = 0; k < n; ++k)
+    {
+      Y[k]    = 0.;
+      int top = n;
+      Flag[k] = k;
+      Lnz[k]  = 0;
+      for (int p = F->Up[k]; p < F->Up[k + 1]; ++p)
+      {
+        int i = F->Ui[p];
+        if (i <= k)
+        {
+          Y[i] += F->Ux[p];
+          int len;
+          for (len = 0; Flag[i] != k; i = F->Parent[i])
+          {
+            Pattern[len++] = i;
+            Flag[i]        = k;
+          }
+          while (len > 0)
+            Pattern[--top] = Pattern[--len];
+        }
+      }
+      F->D[k] = Y[k];
+      Y[k]    = 0.;
+      for (; top < n; ++top)
+      {
+        const int i     = Pattern[top];
+        const double yi = Y[i];
+        Y[i]            = 0.;
+        const int p2    = F->Lp[i] + Lnz[i];
+        for (int p = F->Lp[i]; p < p2; ++p)
+          Y[F->Li[p]] -= F->Lx[p] * yi;
+        const double l_ki = yi / F->D[i];
+        F->D[k] -= l_ki * yi;
+        F->Li[p2] = k;
+        F->Lx[p2] = l_ki;
+        ++Lnz[i];
+      }
+      if (F->D[k] == 0.)
+      {
+        rc = -1;
+        goto done;
+      }
+    }
+  }
+done:
+  free(Lnz);
+  free(Flag);
+  free(Pattern);
+  free(fill);
+  return rc;
+}
+
 long oracle_ldl_lnz(const OracleLdl* F) { return F->lnz; }
 double oracle_ldl_flops(const OracleLdl* F) { return F->flops; }
 

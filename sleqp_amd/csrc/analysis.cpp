@@ -764,8 +764,9 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   // Panels in LEVEL order: the fronts below any level form a prefix of the factor arena.  (The solve-panel items of
   // the device runtime put the panels of the finished bottom levels back to zero behind them, so that the zero fill
   // in front of the next factorisation covers the top levels only.)
+  const bool loff_post = getenv("HIPFACT_LOFF_POSTORDER") != nullptr;
   for (int q = 0; q < ns; ++q) {
-    const int s = P.level_sn[q];
+    const int s = loff_post ? q : P.level_sn[q];
     const int w = sn[s].w, r = P.sn_r[s];
     P.sn_Loff[s] = Loff;
     Loff += ((int64_t)r * w + 1) & ~1LL;

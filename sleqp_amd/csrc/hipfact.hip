@@ -296,7 +296,7 @@ struct hipfact_handle : PlanState {
   int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_levels = 1 << 20;  // at most this many levels in the single-launch top-of-tree factorisation (tests)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
-  bool zero_behind = true;    // solve-panel items put the panels of the bottom levels back to zero (see l_prefix)
+  bool zero_behind = false;   // solve-panel items put the panels of the bottom levels back to zero (see l_prefix): -10 us on the fill, +15 us on the dataflow launch (measured), off
   int factor_top_post = 64;   // levels with at most this many fronts post the pivot block to polling panel workgroups
   int wide_min_rows = 256;    // fronts with at least this many update rows are solved by several workgroups (0: off; one workgroup streams a panel at ~50 GB/s)
   int top_prefetch = 1;       // top-of-tree solve kernels prefetch their panels before the dependency wait
@@ -1969,6 +1969,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_ZERO_BEHIND")) h->zero_behind = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SOLVE_SLICES")) h->solve_slices = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;
@@ -3157,6 +3158,11 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
   if (!strcmp(name, "solve_fused")) {  // 0: the two-launch / per-level solve kernels on the factor panels
     h->solve_fused = value != 0.0;
     invalidate_plans(h);
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "zero_behind")) {  // solve-panel items zero the bottom levels' panels behind them (plan option)
+    if (h->zero_behind != (value != 0.0)) invalidate_plans(h);
+    h->zero_behind = value != 0.0;
     return HIPFACT_OK;
   }
   if (!strcmp(name, "superset_vtable")) {  // 0: hipfact_set_matrix analyses the pattern of K itself (exact-pattern plan cache only)

@@ -188,6 +188,12 @@ class OracleLdl:
         lib().oracle_ldl_solve(self._f, _p(b), _p(x))
         return x
 
+    def refactor(self, data):
+        """Numeric-only refactorisation with new values of the same pattern (symbolic phase reused)."""
+        d = _f64(data)
+        if lib().oracle_ldl_refactor(self._f, _p(self._keep[0]), _p(self._keep[1]), _p(d)) != 0:
+            raise ZeroDivisionError("oracle_ldl_refactor failed (zero pivot)")
+
     def __del__(self):
         try:
             if self._f:

@@ -186,3 +186,25 @@ def test_hess_prod_lower():
     d = np.random.default_rng(0).standard_normal(20)
     y = oracle.hess_prod_lower(20, L.indptr, L.indices, L.data, d)
     assert np.allclose(y, H @ d)
+
+
+def test_sparse_ldl_numeric_refactor_matches_full_factor():
+    """oracle_ldl_refactor (symbolic reused, the `numeric_only` CPU baseline figure) gives the factor of a fresh
+    oracle_ldl_factor on the new values: same solve, bit for bit."""
+    import scipy.sparse as sp
+
+    from sleqp_amd import synth
+
+    J = synth.banded_jacobian(300, 140, 8, 60, 3)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(N)
+    F = oracle.OracleLdl(N, cp, ri, vx)
+    vx2 = vx.copy()
+    off = ri != np.repeat(np.arange(N), np.diff(cp))
+    vx2[off] *= 1.0 + 0.3 * rng.standard_normal(int(off.sum()))
+    F.refactor(vx2)
+    G = oracle.OracleLdl(N, cp, ri, vx2)
+    assert np.array_equal(F.solve(b), G.solve(b))
+    K = synth.kkt_full_matrix(N, cp, ri, vx2)
+    assert np.abs(K @ F.solve(b) - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
