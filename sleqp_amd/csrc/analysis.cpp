@@ -484,6 +484,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   if (const char* e = getenv("HIPFACT_WMAX")) prm.wmax = atoi(e);
   if (const char* e = getenv("HIPFACT_MAX_CHILDREN")) prm.max_children = atoi(e);
   if (const char* e = getenv("HIPFACT_ADOPT")) prm.adopt_leaves = atoi(e) != 0;
+  if (const char* e = getenv("HIPFACT_DENSE_TAU")) prm.dense_tau = atof(e);
   if (const char* e = getenv("HIPFACT_ND_SEP_FRAC")) prm.nd_sep_frac = atof(e);
   if (const char* e = getenv("HIPFACT_RELAX")) {
     double a, b, c;
@@ -545,6 +546,27 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   const int m = P.m;
   const int nx = P.n;
 
+  // ---- dense columns of A: left out of S (their rows would form cliques); handled by the solves
+  std::vector<char> is_dense;
+  if (saddle && prm.dense_tau > 0.0 && prm.dense_max > 0 && m > 0) {
+    const double thr = std::max((double)prm.dense_min, prm.dense_tau * std::sqrt((double)m));
+    std::vector<std::pair<int, int>> cand;  // (-count, column)
+    for (int j = 0; j < nx; ++j) {
+      const int c = Kp[j + 1] - Kp[j] - 1;
+      if ((double)c > thr) cand.push_back({-c, j});
+    }
+    if (!cand.empty()) {
+      std::sort(cand.begin(), cand.end());
+      if ((int)cand.size() > prm.dense_max) cand.resize((size_t)prm.dense_max);
+      is_dense.assign((size_t)nx, 0);
+      for (auto& c : cand) {
+        is_dense[(size_t)c.second] = 1;
+        P.dense_cols.push_back(c.second);
+      }
+      std::sort(P.dense_cols.begin(), P.dense_cols.end());
+    }
+  }
+  const char* dn = is_dense.empty() ? nullptr : is_dense.data();
   // ---- graph of M (saddle: S = A A^T, generic: K + K^T), no diagonal
   Graph g;
   g.n = m;
@@ -565,6 +587,21 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         ar_src[fill[a]] = e;
         ++fill[a];
       }
+    // A row whose ONLY entry lies in a dense column (the unit row of an active bound on that variable, when K's own
+    // pattern is analysed) would vanish from A_s: that column stays an ordinary one (x_j is pinned by the row)
+    if (!is_dense.empty()) {
+      bool changed = false;
+      for (int a = 0; a < m; ++a)
+        if (ar_ptr[a + 1] - ar_ptr[a] == 1 && is_dense[(size_t)ar_col[ar_ptr[a]]]) {
+          is_dense[(size_t)ar_col[ar_ptr[a]]] = 0;
+          changed = true;
+        }
+      if (changed) {
+        P.dense_cols.clear();
+        for (int j = 0; j < nx; ++j)
+          if (is_dense[(size_t)j]) P.dense_cols.push_back(j);
+      }
+    }
     // S = A A^T: rows are independent (count, prefix, fill; one marker array per thread)
     std::vector<int64_t> deg(m + 1, 0);
     parallel_chunks(m, [&](int lo, int hi, int) {
@@ -574,6 +611,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         int64_t c = 0;
         for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
           const int j = ar_col[q];
+          if (dn && dn[j]) continue;
           for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
             const int b = Ki[e] - nx;
             if (mark[b] != a) {
@@ -595,6 +633,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         int64_t o = g.ptr[a];
         for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
           const int j = ar_col[q];
+          if (dn && dn[j]) continue;
           for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
             const int b = Ki[e] - nx;
             if (mark[b] != a) {
@@ -867,6 +906,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
           const int b = perm[k];
           for (int q = ar_ptr[b]; q < ar_ptr[b + 1]; ++q) {
             const int j = ar_col[q];
+            if (dn && dn[j]) continue;
             const int eb = ar_src[q];
             for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
               const int i = iperm[Ki[e] - nx];

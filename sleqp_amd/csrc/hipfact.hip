@@ -28,6 +28,9 @@
 
 // single translation unit: the kernels are compiled together with their launcher
 #include "kernels.hip"
+#define DENSE_COLS_KERNELS
+#include "dense_cols.inc"
+#undef DENSE_COLS_KERNELS
 
 namespace hipfact {
 
@@ -223,6 +226,10 @@ struct PlanState {
   double sp_bytes = 0;
   DevBuf d_SPf, d_SPb, d_sitems, d_xhat, d_sxuoff, d_sxinvoff, d_epoch, d_spart;
   int n_sitems = 0;  // items of the fused solve launch: one per front, row slices for fronts of more than 1024 rows
+  // dense columns of A (dense_cols.inc): left out of S, applied to every solve by a rank-2k correction
+  int nd = 0, dense_cap = 0;
+  DevBuf d_dmask, d_dcols, d_Bq, d_Zq, d_dtmp, d_dG, d_dMinv, d_dw, d_dfix;
+  DevBuf d_Ar_full;  // scaled values of A in pivot order WITH the dense columns (the residual is taken on K itself)
 
   PlanState() = default;
   PlanState(PlanState&&) = default;
@@ -397,6 +404,8 @@ static size_t solve_panel_lds(int wmax) {
   const size_t wp = (size_t)((wmax + 15) & ~15);
   return (wp * (wp + 1) + wp + 8 * 16 * 17 + wp + 1024) * sizeof(double);
 }
+
+static int dense_upload(hipfact_handle* h, size_t vec_bytes);
 
 static int upload_plan(hipfact_handle* h) {
   const Plan& P = h->plan;
@@ -1195,6 +1204,10 @@ static int upload_plan(hipfact_handle* h) {
   HCHECK(h, h->d_rhs.ensure(nb));
   HCHECK(h, h->d_sol.ensure(nb));
   HCHECK(h, h->d_res.ensure(nb));
+  {
+    const int drc = dense_upload(h, nb);
+    if (drc) return drc;
+  }
   HCHECK(h, h->d_info.ensure(INFO_BYTES));  // info words + pivot min / max
   HCHECK(h, h->d_norms.ensure(3 * sizeof(double) * 4096));
   HCHECK(h, h->h_info.ensure(INFO_WORDS * sizeof(int) + 2 * 64 * sizeof(double)));
@@ -1217,6 +1230,9 @@ static int upload_plan(hipfact_handle* h) {
 static inline unsigned long long* minmax_ptr(const hipfact_handle* h) {
   return reinterpret_cast<unsigned long long*>(h->d_info.as<char>() + INFO_WORDS * sizeof(int));
 }
+
+static inline SaddleMaps saddle_maps(const hipfact_handle* h);
+#include "dense_cols.inc"
 
 // this factorisation's solve-panel items zero the panels of the bottom levels behind them
 static bool zero_behind_now(const hipfact_handle* h) {
@@ -1254,7 +1270,8 @@ static int factor_enqueue(hipfact_handle* h) {
       const int nbz = (int)std::min<long long>(2048, std::max<long long>(1, nz16 / (FB * 8)));
       LAUNCH(PC_GATHER, k_row_scale, dim3(nbz + nblocks((long long)P.m * 16)), dim3(FB), 0, P.m,
              h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_src.as<int>(), h->d_Kval.as<double>(), vmap,
-             h->equilibrate ? 1 : 0, h->d_dscale.as<double>(), h->d_Ar_val.as<double>(), h->d_Ksc.as<double>(), kprod,
+             h->nd > 0 ? h->d_dmask.as<int>() : nullptr, h->equilibrate ? 1 : 0, h->d_dscale.as<double>(),
+             h->d_Ar_val.as<double>(), h->nd > 0 ? h->d_Ar_full.as<double>() : nullptr, h->d_Ksc.as<double>(), kprod,
              nbz, reinterpret_cast<double2*>(h->d_L.as<char>() + fill_skip), nz16, h->d_info.as<int>());
     }
   }
@@ -1359,7 +1376,7 @@ static int factor_enqueue(hipfact_handle* h) {
              h->d_sitems.as<SolveItem>() + sp_done, h->d_L.as<double>(), h->d_SPf.as<double>(), h->d_SPb.as<double>());
   }
   HCHECK(h, hipGetLastError());
-  return HIPFACT_OK;
+  return dense_setup_async(h);
 }
 
 template <class F>
@@ -1509,9 +1526,15 @@ static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs =
 
 // z = K^-1 b (acc: z += K^-1 b) without refinement; b, z device vectors in the caller's
 // numbering, b != z
-static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool acc, const int* skip) {
+static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool acc, const int* skip, bool raw = false) {
   const Plan& P = h->plan;
   if (h->N_ext == 0) return;
+  if (h->nd > 0 && !raw) {
+    // dense columns: K_0^-1 b into the scratch vector, then the rank-2k correction writes (or adds) the result
+    solve_once_async(h, b, h->d_dtmp.as<double>(), false, skip, true);
+    dense_correct_async(h, z, acc, skip);
+    return;
+  }
   // fused solve launch: the kernel behind it advances the epoch of its double-buffered exchange slots
   int* epoch = (h->fused_solve && !h->no_dataflow && P.m > 0) ? h->d_epoch.as<int>() : nullptr;
   if (P.saddle) {
@@ -1567,7 +1590,8 @@ static void residual_async(hipfact_handle* h, const double* b, const double* z, 
   if (P.saddle) {
     LAUNCH(PC_RESID, k_residual_saddle, dim3(resid_blocks(P)), dim3(FB), 0, P.n, P.m, h->d_Kp.as<int>(),
            h->d_Ki.as<int>(), h->d_Kval.as<double>(), h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(),
-           h->d_Ar_val.as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl, h->d_norms.as<double>(),
+           (h->nd > 0 ? h->d_Ar_full : h->d_Ar_val).as<double>(), h->d_perm.as<int>(), saddle_maps(h), b, z, res, ctl,
+           h->d_norms.as<double>(),
            first ? 1 : 0, dflag);
   } else {
     LAUNCH(PC_RESID, k_residual_sym, dim3(resid_blocks(P)), dim3(FB), 0, P.N, h->d_Kp.as<int>(), h->d_Ki.as<int>(),
@@ -3266,7 +3290,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor) INFO("vtable_rows", h->vj->rows()) INFO("vtable_retries", h->vtable_retries) INFO("superset_vtable", h->superset_vtable)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor) INFO("dense_columns", h->nd) INFO("vtable_rows", h->vj->rows()) INFO("vtable_retries", h->vtable_retries) INFO("superset_vtable", h->superset_vtable)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

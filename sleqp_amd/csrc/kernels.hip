@@ -3706,9 +3706,10 @@ __global__ __launch_bounds__(SPB) void k_build_solve_panels(const SolveItem* __r
 __global__ __launch_bounds__(FB) void k_row_scale(int m, const int* __restrict__ Ar_ptr,
                                                   const int* __restrict__ Ar_col, const int* __restrict__ Ar_src,
                                                   const double* __restrict__ Kval, const int* __restrict__ vmap,
-                                                  int enable, double* __restrict__ dscale,
-                                                  double* __restrict__ Ar_val, double* __restrict__ Ksc,
-                                                  double* __restrict__ Kprod, int nbz, double2* __restrict__ zero,
+                                                  const int* __restrict__ dmask, int enable, double* __restrict__ dscale,
+                                                  double* __restrict__ Ar_val, double* __restrict__ Ar_full,
+                                                  double* __restrict__ Ksc, double* __restrict__ Kprod, int nbz,
+                                                  double2* __restrict__ zero,
                                                   long long nzero, int* __restrict__ info) {
   if ((int)blockIdx.x < nbz) {
     if (blockIdx.x == 0 && threadIdx.x < INFO_BYTES / 4) info[threadIdx.x] = 0;
@@ -3736,12 +3737,14 @@ __global__ __launch_bounds__(FB) void k_row_scale(int m, const int* __restrict__
         const int e = Ar_src[p];
         const double val = Kval[e];
         const bool fixed = vmap && vmap[Ar_col[p]] >= 0;
+        // a dense column (dense_cols.inc) is masked out of every product of the engine - unless its bound is active
+        const bool dense = dmask && !fixed && dmask[Ar_col[p]] >= 0;
         if (q < KEEP) {
           v[q] = val;
           src[q] = e;
           fx[q] = fixed;
         }
-        if (!fixed) s += val * val;
+        if (!fixed && !dense) s += val * val;
       }
     }
 #pragma unroll
@@ -3770,6 +3773,10 @@ __global__ __launch_bounds__(FB) void k_row_scale(int m, const int* __restrict__
           fixed = vmap && vmap[Ar_col[p]] >= 0;
         }
         val *= d;
+        if (Ar_full) {
+          Ar_full[p] = val;  // the residual is taken on K itself
+          if (!fixed && dmask[Ar_col[p]] >= 0) val = 0.0;
+        }
         Ar_val[p] = val;
         Ksc[e] = val;
         if (Kprod != Ksc) Kprod[e] = fixed ? 0.0 : val;

@@ -34,6 +34,13 @@ struct PlanParams {
   double relax_mid = 0.4;     // ... <= 64
   double relax_big = 0.3;     // ... wider
   int max_children = 4;       // merges must not create fronts with more children (0 = unlimited); = MAXCH of the device
+  // Dense columns of the Jacobian (a variable that appears in a large share of the constraints): every such column
+  // makes the rows it touches a clique of S = A A^T.  Columns with more than max(dense_min, dense_tau sqrt(m)) entries
+  // (at most dense_max of them, the densest first) are left out of S; the device handles them by a low-rank
+  // correction of every solve (hipfact.hip: dense columns).  0 = off.
+  double dense_tau = 4.0;
+  int dense_min = 64;
+  int dense_max = 64;
   bool adopt_leaves = true;   // childless fronts that are not adjacent to their parent are renumbered and merged into it
   bool force_generic = false;
 };
@@ -86,6 +93,7 @@ struct Plan {
   std::vector<int> Ar_col;   // column (x index)
   std::vector<int> Ar_src;   // index into Kval
   std::vector<int> Kc_y;     // per K entry in columns < n: pivot position of its y row, -1 for the diagonal
+  std::vector<int> dense_cols;  // x columns left out of S = A A^T (ascending); see PlanParams::dense_tau
 
   // ---- statistics
   int64_t nnzL = 0;       // entries of L incl. diagonal (M part, dense panels)

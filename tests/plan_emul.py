@@ -15,7 +15,7 @@ import numpy as np
 
 _NAMES = [
     "Kp", "Ki", "perm", "iperm", "Mp", "Mi", "Mtarget", "prod_ptr", "prod_a", "prod_b", "src", "sn_c0", "sn_r",
-    "sn_rowptr", "sn_rows", "sn_parent", "sn_level", "sn_Loff", "sn_Uoff", "sn_uoff", "child_ptr", "child_idx",
+    "sn_rowptr", "sn_rows", "sn_parent", "sn_level", "sn_Loff", "sn_Uoff", "sn_uoff", "child_ptr", "child_idx", "dense_cols",
     "rel_ptr", "rel", "level_ptr", "level_sn", "Ar_ptr", "Ar_col", "Ar_src", "Kc_y",
 ]
 _SCALARS = [

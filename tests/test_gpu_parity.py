@@ -597,6 +597,117 @@ def test_vtable_set_matrix_reuses_the_superset_plan(fact):
     assert rel_err(aug3.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL
 
 
+def _with_dense_columns(J, k, seed, frac=1.0):
+    """J plus k columns that have an entry in (a share `frac` of) every row."""
+    m, n = J.shape
+    rng = np.random.default_rng(seed)
+    cols = np.sort(rng.choice(n, k, replace=False))
+    rows = np.flatnonzero(rng.random(m) < frac) if frac < 1.0 else np.arange(m)
+    D = sp.csc_matrix((rng.standard_normal(rows.size * k), (np.tile(rows, k), np.repeat(cols, rows.size))), shape=(m, n))
+    Jd = (J + D).tocsc()
+    Jd.sort_indices()
+    return Jd, cols
+
+
+@pytest.mark.parametrize("vtable", [1, 0], ids=["row_dictionary", "exact_pattern"])
+@pytest.mark.parametrize("k", [1, 4, 16])
+def test_dense_jacobian_columns_vs_oracle(fact, k, vtable):
+    """the reference's backends order K itself (fact_ma57.c:314-345, AMD on K) and keep a variable that
+    appears in every constraint away from the fill.  Here such columns are left out of S = A A^T and applied to
+    every solve as a low-rank correction (dense_cols.inc): the plan is as sparse as without them, and the three
+    AugJac solves agree with the oracle - with and without active bounds on the dense variables themselves."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 1500, 700
+    J0 = synth.banded_jacobian(n, m, 10, 80, 17)
+    J, dcols = _with_dense_columns(J0, k, 5, frac=1.0 if k < 16 else 0.6)
+    rng = np.random.default_rng(k)
+    fact.set_option("superset_vtable", vtable)
+    aug = StandardAugJac(n, fact, device_assembly=False)
+    g = rng.standard_normal(n)
+    vi, ci, W = _ws(n, m, rng, 1.0, 0.0)
+    N0, c0, r0, d0 = oracle.fill_aug_jac(n, m, J0.indptr, J0.indices, J0.data, vi, ci)
+    base = HipFactPlanStats(N0, c0, r0, d0)
+    for step in range(3):
+        if step == 1:  # rows leave, ordinary bounds become active
+            vi, ci, W = _ws(n, m, rng, 0.93, 0.03)
+        if step == 2:  # ... and a bound on one of the dense variables themselves
+            vi, ci, W = _ws(n, m, rng, 0.97, 0.0)
+            vi[:] = -1
+            vi[dcols[0]] = 0
+            ci[ci >= 0] += 1
+            W += 1
+        aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        assert np.array_equal(aug.K.cols, kc) and np.array_equal(aug.K.rows, kr)
+        if step < 2:
+            assert fact.info("dense_columns") == k
+        if step == 0:
+            # as sparse as the plan without the dense columns (the bar: within 1.2x)
+            assert fact.info("nnzL") <= 1.2 * base.nnzL, (fact.info("nnzL"), base.nnzL)
+        ref = oracle.OracleFact(N, kc, kr, kd)
+        idx, val = ref.project_nullspace(n, np.arange(n), g)
+        assert rel_err(aug.project_nullspace(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL, step
+        idx, val = ref.solve_lsq(n, np.arange(n), g)
+        assert rel_err(aug.solve_lsq(SleqpVec.from_raw(g)).to_raw(), oracle.vec_to_raw(W, idx, val)) <= REL_TOL, step
+        c = rng.standard_normal(W)
+        idx, val = ref.solve_min_norm(n, np.arange(W), c)
+        assert rel_err(aug.solve_min_norm(SleqpVec.from_raw(c)).to_raw(), oracle.vec_to_raw(n, idx, val)) <= REL_TOL, step
+        b = rng.standard_normal(N)
+        ref.solve_dense(b)
+        fact.solve(b)
+        assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL, step
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        assert scaled_residual(K, fact.solution_raw(0, N), b) <= 1e-12
+
+
+class HipFactPlanStats:
+    """nnz(L) of the plan for a matrix (host analysis only, through the plan ABI)."""
+
+    def __init__(self, N, kc, kr, kd):
+        from plan_emul import Plan
+        from sleqp_amd import _lib
+
+        p = Plan(_lib.load(), N, kc, kr, kd)
+        self.nnzL = p.nnzL
+        self.dense = len(p.dense_cols)
+
+
+@pytest.mark.timeout(240)
+def test_dense_jacobian_columns_at_full_size():
+    """BASELINE configs[3] (n = 1e5, m = 5e4, nnz(J) = 1e6) plus 1, 4 and 16 dense columns: the analysis no longer
+    refuses the pattern, nnz(L) stays within 1.2x of the plan without them, and the solution agrees with the
+    oracle's sparse LDL^T (which orders K itself) to 1e-8; scaled residual 1e-12."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 100000, 50000
+    J0 = synth.banded_jacobian(n, m, 20, 200, 0)
+    vi, ci, _ = synth.working_set_all_rows(n, m)
+    N0, c0, r0, d0 = synth.kkt_lower_from_jacobian(J0, vi, ci)
+    base = HipFactPlanStats(N0, c0, r0, d0).nnzL
+    from sleqp_amd.fact import HipFact
+
+    for k in (1, 4, 16):
+        J, dcols = _with_dense_columns(J0, k, 3)
+        N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+        fact = HipFact(device=0)  # (a fresh row dictionary: the rows of the previous matrix would stay in the structure)
+        fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+        assert fact.info("dense_columns") == k and fact.info("nnzL") <= 1.2 * base
+        b = np.random.default_rng(k).standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        K = synth.kkt_full_matrix(N, cp, ri, vx)
+        assert scaled_residual(K, z, b) <= 1e-12
+        if k == 4:
+            # the oracle factors K itself, in an order that keeps the dense variables for last (what an ordering on K
+            # finds by itself: fact_ma57.c:314-345; in the natural order their columns would fill the factor)
+            perm = np.r_[np.setdiff1d(np.arange(n), dcols), n + np.arange(N - n), dcols].astype(np.int32)
+            zo = oracle.OracleLdl(N, cp, ri, vx, perm=perm).solve(b)
+            assert rel_err(z, zo) <= 1e-8
+        fact.free()
+
+
 def test_pattern_lru_for_set_matrix(fact):
     """Unmodified standard_aug_jac.c in front of the backend: K's pattern changes with the working
     set; patterns seen before are served from the plan LRU (no analysis, no upload, no graph capture)."""
