@@ -41,7 +41,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
-PROFILE_TAG = "r2"
+PROFILE_TAG = "r3"
+KERNEL_SOURCES = ("kernels.hip", "hipfact.hip", "dense_cols.inc", "vtable_superset.inc")  # hashed into the PMC files
 
 
 def make_problem(workload: str, seed: int):
@@ -231,12 +232,12 @@ def cpu_baseline(N, cp, ri, vx, b, budget_s=12.0):
 
 def kernels_sha():
     h = hashlib.sha256()
-    for name in ("kernels.hip", "hipfact.hip"):
+    for name in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, "sleqp_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
-def load_traffic(kernel_name):
+def load_traffic(kernel_name, workload=None):
     """HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
     gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE).  Only valid for the kernel sources it was measured on:
     the file records their hash, a mismatch yields null instead of a stale number."""
@@ -246,6 +247,8 @@ def load_traffic(kernel_name):
         return None, "no profiles/%s_pmc_traffic.json" % PROFILE_TAG
     if pmc.get("_kernels_sha16") != kernels_sha():
         return None, "profiles/%s_pmc_traffic.json was measured on other kernel sources" % PROFILE_TAG
+    if workload is not None and pmc.get("_workload", "banded_n1e5_m5e4") != workload:
+        return None, "profiles/%s_pmc_traffic.json was measured on workload %s" % (PROFILE_TAG, pmc.get("_workload"))
     rec = pmc.get(kernel_name)
     if not rec:
         return None, "kernel not in the PMC file"
@@ -253,7 +256,7 @@ def load_traffic(kernel_name):
         "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernels sha %s" % pmc["_kernels_sha16"]
 
 
-def load_spmv_traffic():
+def load_spmv_traffic(workload=None):
     """HBM bytes per launch of the three sparse products, from PMC passes that run ONE product each
     (`bench.py --spmv-only NAME` under rocprofv3 --pmc; the products share a kernel template)."""
     try:
@@ -262,6 +265,8 @@ def load_spmv_traffic():
         return None, "no profiles/%s_pmc_spmv.json" % PROFILE_TAG
     if pmc.get("_kernels_sha16") != kernels_sha():
         return None, "profiles/%s_pmc_spmv.json was measured on other kernel sources" % PROFILE_TAG
+    if workload is not None and pmc.get("_workload", "banded_n1e5_m5e4") != workload:
+        return None, "profiles/%s_pmc_spmv.json was measured on workload %s" % (PROFILE_TAG, pmc.get("_workload"))
     return pmc, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, one pass per counter and product, kernels sha %s" % pmc["_kernels_sha16"]
 
 
@@ -637,7 +642,7 @@ def main():
         rngh = np.random.default_rng(7)
         Hl, Jd, Hd, xs, ys, ops = spmv_setup(fact, J, n, m, dev, rngh)
         spmv = {}
-        pmc_spmv, pmc_note = load_spmv_traffic()
+        pmc_spmv, pmc_note = load_spmv_traffic(args.workload)
         for name, M, trans, (r, c, nz) in ops:
             for _ in range(5):
                 M.mult_device(trans, xs.data_ptr(), ys.data_ptr())
@@ -720,7 +725,7 @@ def main():
                                                           "factorC", "factorD", "factorT", "spanel") if k in prof)
         traffic, traffic_note = (None, "workload other than the profiled one")
         if args.workload == "banded_n1e5_m5e4":
-            traffic, traffic_note = load_traffic(kernel_names.get(dom, dom))
+            traffic, traffic_note = load_traffic(kernel_names.get(dom, dom), args.workload)
         out = {
             "metric": "KKT factor+solve/sec (numeric refactor + 1 solve with device-controlled refinement, inputs resident in HBM)",
             "value": rep.aggregate_rate(args.steps, t_max),
@@ -769,7 +774,7 @@ def main():
         if args.workload == "banded_n1e5_m5e4":
             parts, note = [], None
             for kname in ("k_solve_tree", "void k_x_saddle<false>", "k_residual_saddle"):
-                tr, note = load_traffic(kname)
+                tr, note = load_traffic(kname, args.workload)
                 parts.append(tr)
             if all(v is not None for v in parts):
                 out["solve_only"]["rocprof_hbm_bytes"] = sum(parts)

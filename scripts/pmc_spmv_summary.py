@@ -25,7 +25,8 @@ for op in ("J_x", "JT_y", "H_sym_x"):
     print("%-10s %6d %16.0f %16.0f %16.0f" % (op, nf, f, 2 * f, w))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for name in ("kernels.hip", "hipfact.hip"):
+for name in ("kernels.hip", "hipfact.hip", "dense_cols.inc", "vtable_superset.inc"):  # = bench.py KERNEL_SOURCES
     h.update(open(os.path.join(root, "sleqp_amd", "csrc", name), "rb").read())
 res["_kernels_sha16"] = h.hexdigest()[:16]
+res["_workload"] = os.environ.get("HIPFACT_PROFILE_WORKLOAD", "banded_n1e5_m5e4")  # the passes ran bench.py's default workload
 json.dump(res, open(dst, "w"), indent=1)

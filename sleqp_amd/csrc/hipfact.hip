@@ -1610,7 +1610,22 @@ static void flush_decide(hipfact_handle* h) {
   h->decide_deferred = false;
 }
 
-static void drop_graphs(hipfact_handle* h) { h->graphs.clear(); }
+// (the parked states too: their graphs captured option values - refine_tol, equilibrate, launch variants - by value)
+static void drop_graphs(hipfact_handle* h) {
+  h->graphs.clear();
+  for (auto& st : h->cache) st->graphs.clear();
+}
+// the solve graphs of the active state only (they capture the length of the caller's vectors)
+static void drop_solve_graphs(hipfact_handle* h) {
+  std::vector<GraphEntry> keep;
+  for (auto& g : h->graphs.v) {
+    if (g.kind == 0)
+      keep.push_back(g);
+    else
+      (void)hipGraphExecDestroy(g.exec);
+  }
+  h->graphs.v.swap(keep);
+}
 
 // options that change the plan or the schedule: every cached state is stale
 static void invalidate_plans(hipfact_handle* h) {
@@ -2061,8 +2076,20 @@ int hipfact_set_matrix(hipfact_handle* h, int N, const int* colptr, const int* r
     const bool could_fall_back = !h->no_dataflow;
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpyAsync(h->d_Kval.p, vals, (size_t)nnz_in * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = factor_async(h))) return rc;
-    if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) return rc;
+    // (the copy reads the caller's array: no return, error or not, while it may be in flight; and the queued work
+    // runs on the active state's buffers and graphs: it is awaited before that state is parked or swapped)
+    if ((rc = factor_async(h))) {
+      (void)hipStreamSynchronize(h->stream);
+      return rc;
+    }
+    const bool same_active = h->plan.N == N && h->plan.nnzK == nnz_in &&
+                             memcmp(h->plan.Kp.data(), colptr, (size_t)(N + 1) * sizeof(int)) == 0 &&
+                             (nnz_in == 0 || memcmp(h->plan.Ki.data(), rowidx, (size_t)nnz_in * sizeof(int)) == 0);
+    if (!same_active) HCHECK(h, hipStreamSynchronize(h->stream));
+    if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) {
+      (void)hipStreamSynchronize(h->stream);
+      return rc;
+    }
     if (h->analyses == analyses && h->plan_swaps == swaps) return check_factor(h, could_fall_back);
     HCHECK(h, hipStreamSynchronize(h->stream));  // another plan is active now: start over on it
   } else if ((rc = ensure_plan(h, N, colptr, rowidx, vals))) {
@@ -2161,14 +2188,23 @@ int hipfact_solve_sparse(hipfact_handle* h, int dim, int nnz, const int* indices
       pv = sv;
       pi = si;
     }
-    HCHECK(h, hipMemcpyAsync(h->d_sp_val.p, pv, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(h->d_sp_idx.p, pi, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (borrowed) HCHECK(h, hipEventRecord(h->ev_fork, h->stream));
+    hipError_t ce = hipMemcpyAsync(h->d_sp_val.p, pv, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (ce == hipSuccess)
+      ce = hipMemcpyAsync(h->d_sp_idx.p, pi, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (ce == hipSuccess && borrowed) ce = hipEventRecord(h->ev_fork, h->stream);
+    if (ce != hipSuccess) {
+      (void)hipStreamSynchronize(h->stream);  // a copy out of the caller's arrays may be in flight
+      HCHECK(h, ce);
+    }
     hipLaunchKernelGGL(k_scatter_sparse, dim3(nblocks(nnz)), dim3(FB), 0, h->stream, nnz, h->d_sp_idx.as<int>(),
                        h->d_sp_val.as<double>(), h->d_rhs.as<double>());
   }
   rc = solve_async(h, h->d_rhs.as<double>(), h->d_sol.as<double>());
-  if (borrowed) HCHECK(h, hipEventSynchronize(h->ev_fork));
+  if (borrowed) {
+    const hipError_t se = hipEventSynchronize(h->ev_fork);
+    if (se != hipSuccess) (void)hipStreamSynchronize(h->stream);
+    if (rc == HIPFACT_OK) HCHECK(h, se);
+  }
   return rc;
 }
 
@@ -2389,6 +2425,8 @@ static int superset_refactor(hipfact_handle* h, int n, int m_total, const int* j
     if ((rc = build_superset_plan(h, n, m_total, j_colptr, j_rowidx, sidx, ms))) return rc;
   }
   h->maps_on = true;
+  // (a solve graph whose right-hand side and solution alias captured a copy of N_ext doubles)
+  if (h->N_ext != N) drop_solve_graphs(h);
   h->N_ext = N;
   h->n_bounds = nav;
   const Plan& P = h->plan;

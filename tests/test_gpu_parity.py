@@ -110,6 +110,11 @@ def _judge(fact, N, kc, kr, kd, b, tag):
     return "ok"
 
 
+# expected outcome of every draw of the sweep below ("S": the working set is numerically rank deficient - both the
+# device and the oracle must say so, _judge checks it): pinned per seed, not a count
+SWEEP_OUTCOMES = ["singular" if c == "S" else "ok" for c in "ooooSoooooooSoooooooSooo"]
+
+
 def test_random_sweep_vs_oracle(fact):
     """Seeded sweep over shapes, densities, active bounds and kernel configurations (per-level
     launches / single-launch top of the tree, pull / scatter extend-add): every solution against
@@ -131,7 +136,7 @@ def test_random_sweep_vs_oracle(fact):
         fact.set_option("pull_max_children", [4, 0][(trial // 3) % 2])
         b = rng.standard_normal(N)
         outcomes.append(_judge(fact, N, kc, kr, kd, b, (trial, n, m, kind, frac)))
-    assert outcomes.count("ok") >= 16, outcomes
+    assert outcomes == SWEEP_OUTCOMES, "".join("o" if o == "ok" else "S" for o in outcomes)
 
 
 def test_graded_conditioning_vs_oracle(fact):
