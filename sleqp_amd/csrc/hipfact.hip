@@ -31,6 +31,9 @@
 #define DENSE_COLS_KERNELS
 #include "dense_cols.inc"
 #undef DENSE_COLS_KERNELS
+#define KRYLOV_DEVICE_KERNELS
+#include "krylov_device.inc"
+#undef KRYLOV_DEVICE_KERNELS
 
 namespace hipfact {
 
@@ -197,6 +200,7 @@ struct PlanState {
   int refine_inline = 1;      // correction passes currently carried by the solve graphs
   int seq_at_factor = 0;      // handle's solve_seq at the time of the last factorisation
   bool inline_probe = true;   // the first solve of this factorisation has not been looked at yet
+  bool wc_hint = false;       // the previous factorisation of this plan was judged well-conditioned (first pass enough)
   GraphList graphs;
   int ftop_level = 1 << 30, ftop_count = 0;
   size_t ftop_lds = 0;
@@ -255,6 +259,7 @@ struct hipfact_handle : PlanState {
   bool chain_fuse = true;         // single-front levels of a dense chain: pivot + panel items as one small dataflow launch
   bool solve_slices = true;       // fused solve: fronts whose panel share does not fit the registers of one item are row-sliced
   bool speculate = true;          // set_matrix: queue values + factorisation before the pattern comparison has finished
+  bool xupd_fused = false;       // ... and its last workgroups do the back substitution of the leaf columns (one launch per solve): measured 2 us SLOWER per solve than the separate 9 us launch (the polling loads), off
   bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
@@ -285,6 +290,12 @@ struct hipfact_handle : PlanState {
   long num_refined = 0;          // solves that applied at least one correction pass
   long num_passes = 0;           // correction passes applied in total
   bool decide_lazy = true;       // verdict of a solve without correction passes delivered by the next tree launch
+  // Once a factorisation has been judged well-conditioned (its solves meet the tolerance in the first pass with room
+  // to spare: no correction pass in their graph), the residual of K z = b is checked on every k-th solve only - the
+  // reference's MA57 path never checks (fact_ma57.c:18).  1: every solve.
+  int refine_check_every = 8;
+  bool skip_resid_now = false;   // (the solve being queued is one of the unchecked ones)
+  long solves_since_check = 0;
   bool decide_deferred = false;  // ... and such a verdict is outstanding
   bool ctl_pending = false;      // the control block of the last solve has not been looked at yet
   const double* last_b = nullptr;
@@ -322,8 +333,10 @@ struct hipfact_handle : PlanState {
   // assembly
   DevBuf d_jp, d_ji, d_jx, d_vi, d_ci, d_cnt, d_akp, d_aki, d_akx;
   // projected CG
-  DevBuf d_cg_b, d_cg_z, d_cg_vec, d_cg_dots;
-  PinBuf h_cg_dots, h_hv;
+  DevBuf d_cg_b, d_cg_z, d_cg_vec, d_cg_dots, d_cg_ctl;
+  PinBuf h_cg_dots, h_hv, h_cg_ctl;
+  bool cg_device_loop = true;  // projected CG with the loop control on the device (krylov_device.inc)
+  long cg_device_runs = 0, cg_device_fallbacks = 0;
   DevBuf d_lz_Q, d_lz_b, d_lz_coef;  // generalised Lanczos: basis (n x cap), three rotating right-hand sides, coefficients
 };
 
@@ -1397,9 +1410,13 @@ static int factor_async(hipfact_handle* h) {
   h->factor_checked = false;
   h->solved = false;
   h->ctl_pending = false;
-  h->refine_inline = h->refine_steps;
+  // a plan whose previous factorisation needed no correction pass starts without one in its solve graphs (an SQP run
+  // refactors the same pattern with slowly changing values); the first solve is checked as always, and a solve that
+  // does need a pass is continued at the next synchronising entry point, which also puts the pass back
+  h->refine_inline = (h->wc_hint && h->refine_adaptive) ? 0 : h->refine_steps;
   h->inline_probe = true;
   h->seq_at_factor = h->solve_seq;
+  h->solves_since_check = 0;
   return HIPFACT_OK;
 }
 
@@ -1485,16 +1502,20 @@ static inline SaddleMaps saddle_maps(const hipfact_handle* h) {
 
 // M y = t on the device (y in: t in pivot order, out: solution); skip: device flag that turns
 // every launch into a no-op (correction passes of a solve that has already converged)
-static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs = nullptr) {
+static void solve_m_async(hipfact_handle* h, const int* skip, const RhsIn* rhs = nullptr, const XupdIn* xup = nullptr) {
   const Plan& P = h->plan;
   if (h->fused_solve && !h->no_dataflow) {
-    // (one workgroup more than items: it delivers the deferred verdict of the previous solve, if any)
-    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * h->n_sitems + 1), dim3(ST), 0, h->d_sitems.as<SolveItem>(), h->n_sitems,
+    // (one workgroup more than items: it delivers the deferred verdict of the previous solve, if any; behind it the
+    // workgroups of the x update, when it rides in this launch)
+    XupdIn X;
+    memset(&X, 0, sizeof(X));
+    if (xup) X = *xup;
+    LAUNCH(PC_TREE, k_solve_tree, dim3(2 * h->n_sitems + 1 + X.nblocks), dim3(ST), 0, h->d_sitems.as<SolveItem>(), h->n_sitems,
            h->d_SPf.as<double>(), h->d_SPb.as<double>(), h->d_sxuoff.as<long long>(), h->d_sxinvoff.as<int>(),
            h->d_inv.as<int>(), h->d_rows.as<int>(), h->d_y.as<double>(),
            h->d_xhat.as<double>(), h->d_uvec.as<double>(), h->d_ysol.as<double>(), P.m, h->d_epoch.as<int>(),
            h->d_info.as<int>(), skip, rhs ? *rhs : RhsIn{nullptr, nullptr, nullptr, nullptr, SaddleMaps{nullptr, nullptr, nullptr, 0}, nullptr},
-           decide_in(h), h->d_spart.as<double>());
+           decide_in(h), h->d_spart.as<double>(), X);
     return;
   }
   const int ltop = h->no_dataflow ? P.nlevels : std::min(h->top_level, P.nlevels);
@@ -1540,6 +1561,24 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
   if (P.saddle) {
     const SaddleMaps M = saddle_maps(h);
     if (P.m > 0) {
+      if (h->fused_solve && !h->no_dataflow && h->rhs_fused && h->xupd_fused && P.n > 0) {
+        // ... and its last workgroups the back substitution of the leaf columns: the whole solve is ONE launch
+        const RhsIn R{h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b};
+        XupdIn X;
+        memset(&X, 0, sizeof(X));
+        X.n = P.n;
+        X.Kp = h->d_Kp.as<int>();
+        X.Ksc = h->d_Ksc.as<double>();
+        X.Kc_y = h->d_Kc_y.as<int>();
+        X.perm = h->d_perm.as<int>();
+        X.M = M;
+        X.b = b;
+        X.z = z;
+        X.acc = acc ? 1 : 0;
+        X.nblocks = std::max(1, std::min(256, (P.n + 4 * (ST / 8) - 1) / (4 * (ST / 8))));
+        solve_m_async(h, skip, &R, &X);
+        return;
+      }
       if (h->fused_solve && !h->no_dataflow && h->rhs_fused) {
         // the forward items of the single launch form their own rows of the right-hand side
         const RhsIn R{h->d_Ar_ptr.as<int>(), h->d_Ar_col.as<int>(), h->d_Ar_val.as<double>(), h->d_perm.as<int>(), M, b};
@@ -1702,7 +1741,7 @@ static int solve_enqueue(hipfact_handle* h, const double* b, double* z) {
     bb = h->d_rhs.as<double>();
   }
   solve_once_async(h, bb, z, false, nullptr);
-  if (h->refine_steps > 0) {
+  if (h->refine_steps > 0 && !h->skip_resid_now) {
     residual_async(h, bb, z, h->d_res.as<double>(), true, defers_decide(h));
     return correct_enqueue(h, bb, z, h->refine_inline);
   }
@@ -1721,20 +1760,35 @@ static int solve_async(hipfact_handle* h, const double* b, double* z) {
     // continued at the next synchronising entry point, which also puts the pass back.
     const RefineCtl* hc = h->h_ctl.as<RefineCtl>();
     if (__atomic_load_n(&hc->seq, __ATOMIC_ACQUIRE) == h->solve_seq) {
-      if (hc->done && hc->status == 0 && hc->iters == 0 && hc->omega <= 0.25 * hc->tol) h->refine_inline = 0;
+      if (hc->done && hc->status == 0 && hc->iters == 0 && hc->omega <= 0.25 * hc->tol) {
+        h->refine_inline = 0;
+        h->wc_hint = true;
+      } else {
+        h->wc_hint = false;
+        h->refine_inline = std::max(h->refine_inline, std::min(h->refine_steps, 1));
+      }
       h->inline_probe = false;
     }
   }
   const bool defer = defers_decide(h);
+  // (defer <=> the factorisation has been judged well-conditioned: the first pass alone met a quarter of the tolerance)
+  const bool unchecked = defer && (!h->inline_probe || h->wc_hint) && h->refine_check_every > 1 &&
+                         (h->solves_since_check % h->refine_check_every) != 0;
+  h->solves_since_check = unchecked ? h->solves_since_check + 1 : 1;
   if (!(h->fused_solve && !h->no_dataflow && h->plan.m > 0 && h->plan.saddle)) flush_decide(h);  // no tree launch to deliver it
-  int rc = run_cached(h, 1, b, z, [&] { return solve_enqueue(h, b, z); },
-                      h->refine_steps > 0 ? (defer ? -2 : h->refine_inline) : -1);
+  h->skip_resid_now = unchecked;
+  // (an unchecked steady-state solve is two launches: queued directly - replaying a two-node graph measures 4-5 us
+  // slower per solve than the launches themselves)
+  int rc = unchecked ? solve_enqueue(h, b, z)
+                     : run_cached(h, 1, b, z, [&] { return solve_enqueue(h, b, z); },
+                                  h->refine_steps > 0 ? (defer ? -2 : h->refine_inline) : -1);
+  h->skip_resid_now = false;
   if (rc) return rc;
-  h->decide_deferred = defer;  // (the tree launch of this solve has delivered an older one)
+  if (!unchecked) h->decide_deferred = defer;  // (the tree launch of this solve has delivered an older one)
   h->num_solve++;
   h->solved = true;
-  if (h->refine_steps > 0) h->solve_seq++;
-  h->ctl_pending = h->refine_steps > 0;
+  if (h->refine_steps > 0 && !unchecked) h->solve_seq++;
+  h->ctl_pending = h->refine_steps > 0 && (!unchecked || h->ctl_pending);
   h->last_b = (b == z) ? h->d_rhs.as<double>() : b;
   h->last_z = z;
   return HIPFACT_OK;
@@ -1766,6 +1820,14 @@ static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
   }
   h->ctl_pending = false;
   h->last_ctl = c;
+  if (h->inline_probe && h->refine_adaptive && h->refine_steps > 0) {
+    // (the verdict of the first solve of this factorisation, read here instead of at the next solve's peek)
+    if (c.done && c.status == 0 && c.iters == 0 && c.omega <= 0.25 * c.tol) {
+      h->refine_inline = 0;
+      h->wc_hint = true;
+    }
+    h->inline_probe = false;
+  }
   if (continued) *continued = more > 0;
   // A refinement that STALLS on a row-dictionary structure which carries rows outside the working set (unit pivots
   // that take part in the ordering): for a nearly rank-deficient working set the quality of the statically pivoted
@@ -1780,7 +1842,10 @@ static int finish_solve(hipfact_handle* h, bool* continued = nullptr) {
   if (c.iters > 0) h->num_refined++;
   h->num_passes += c.iters;
   // the next solves of this factorisation carry as many passes in their graph as this one needed
-  if (more > 0) h->refine_inline = std::min(std::max(h->refine_inline, c.iters), 4);
+  if (more > 0) {
+    h->refine_inline = std::min(std::max(h->refine_inline, c.iters), 4);
+    h->wc_hint = false;
+  }
   if (h->refine_adaptive && c.status != 2 && c.omega > h->fail_omega) {
     char buf[200];
     snprintf(buf, sizeof buf,
@@ -2010,6 +2075,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_ZERO_BEHIND")) h->zero_behind = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_XUPD_FUSED")) h->xupd_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SOLVE_SLICES")) h->solve_slices = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_DECIDE_LAZY")) h->decide_lazy = atoi(s) != 0;
@@ -2822,6 +2888,8 @@ static int tr_args_ok(hipfact_handle* h, const HessOp& op, const double* gradien
   return HIPFACT_OK;
 }
 
+#include "krylov_device.inc"
+
 static int steihaug_impl(hipfact_handle* h, const HessOp& op, const double* gradient, double trust_radius,
                          double rel_tol, int max_iter, double* newton_step, double* tr_dual, int* iterations) {
   int rc;
@@ -2873,7 +2941,28 @@ static int steihaug_impl(hipfact_handle* h, const HessOp& op, const double* grad
   } while (cont);
   double d_nrm_sq = dots[0], r_dot_g = dots[1];
   double z_nrm_sq = 0.0;
+  bool dev_used = false;
   if (!(d_nrm_sq < rel_tol_sq)) {
+    bool touched = false;
+    int dstate = 0, dits = 0;
+    if ((rc = steihaug_device_loop(h, op.hess, n, r_dot_g, rel_tol_sq, rad_sq, max_iter, r, h->d_cg_z.as<double>(), z, d, Bd, grad,
+                                   &dev_used, &touched, &dstate, &dits)))
+      return rc;
+    if (dev_used) {
+      h->cg_device_runs++;
+      it = dits;
+      boundary = (dstate == 2);
+      if (dstate == 4) HCHECK(h, hipMemsetAsync(z, 0, nb, st));  // iteration cap: the step stays cleared (see below)
+    } else if (touched) {
+      // a projection did not meet the tolerance unchecked: once more from the start with the host in the loop
+      h->cg_device_fallbacks++;
+      h->cg_device_loop = false;
+      rc = steihaug_impl(h, op, gradient, trust_radius, rel_tol, max_iter, newton_step, tr_dual, iterations);
+      h->cg_device_loop = true;
+      return rc;
+    }
+  }
+  if (!dev_used && !(d_nrm_sq < rel_tol_sq)) {
     for (it = 0;; ++it) {
       if (max_iter != -1 && it >= max_iter) {
         // the reference leaves newton_step cleared when the iteration cap is hit before any of
@@ -3189,6 +3278,19 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->chain_fuse = value != 0.0;
     return HIPFACT_OK;
   }
+  if (!strcmp(name, "cg_device_loop")) {  // 0: the host reads the dot products of every CG iteration (steihaug_impl)
+    h->cg_device_loop = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "xupd_fused")) {  // 0: x = b_x - A^T y as a launch of its own behind the tree (k_x_saddle)
+    if (h->xupd_fused != (value != 0.0)) drop_graphs(h);
+    h->xupd_fused = value != 0.0;
+    return HIPFACT_OK;
+  }
+  if (!strcmp(name, "refine_check_every")) {  // residual check on every k-th solve of a well-conditioned factorisation
+    h->refine_check_every = std::max(1, (int)value);
+    return HIPFACT_OK;
+  }
   if (!strcmp(name, "decide_lazy")) {  // 0: every solve graph ends with its own verdict launch
     if (h->decide_lazy != (value != 0.0)) {
       flush_decide(h);
@@ -3328,7 +3430,7 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value) {
   INFO("analysis_s", P.t_total) INFO("order_s", P.t_order) INFO("symbolic_s", P.t_symbolic)
   INFO("num_zero_pivots", h->info_host[INFO_ZERO_PIVOT]) INFO("num_neg_pivots", h->info_host[INFO_NEG_PIVOT])
   INFO("cache_hits", h->cache_hits) INFO("plan_swaps", h->plan_swaps) INFO("plans_cached", h->cache.size())
-  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor) INFO("dense_columns", h->nd) INFO("vtable_rows", h->vj->rows()) INFO("vtable_retries", h->vtable_retries) INFO("superset_vtable", h->superset_vtable)
+  INFO("no_dataflow", h->no_dataflow) INFO("dataflow_fallbacks", h->dataflow_fallbacks) INFO("fused_solve", h->fused_solve) INFO("spanel_folded", h->sp_folded) INFO("solve_items", h->n_sitems) INFO("chain_levels_fused", [&] { int c = 0; for (const LevelInfo& li : h->levels) c += li.mini_cnt > 0; return c; }()) INFO("solve_panel_bytes", h->sp_bytes) INFO("N_internal", P.N) INFO("maps_on", h->maps_on) INFO("m_struct", h->m_struct) INFO("analyses", h->analyses) INFO("num_factor", h->num_factor) INFO("cg_device_runs", h->cg_device_runs) INFO("cg_device_fallbacks", h->cg_device_fallbacks) INFO("dense_columns", h->nd) INFO("vtable_rows", h->vj->rows()) INFO("vtable_retries", h->vtable_retries) INFO("superset_vtable", h->superset_vtable)
   INFO("num_solve", h->num_solve) INFO("num_refined", h->num_refined) INFO("refine_adaptive", h->refine_adaptive)
   INFO("num_passes", h->num_passes) INFO("last_omega", h->last_ctl.omega) INFO("last_iters", h->last_ctl.iters)
   INFO("last_status", h->last_ctl.status) INFO("last_tol", h->last_ctl.tol) INFO("kappa_est", h->last_ctl.kappa)

@@ -3495,6 +3495,65 @@ __device__ __forceinline__ void dev_solve_bwd(const SolveItem& T, const double* 
   }
 }
 
+// The back substitution of the leaf columns, z_x = b~_x - A^^T y^ and z_y = D y^ (k_x_saddle), as the last
+// workgroups of the fused solve launch: they poll the solution copy the backward items post (ysol) instead of
+// waiting for a kernel boundary - the boundary behind the tree cost more than the 9 us of the product itself
+// (two launches per steady-state solve: 104 us, of which 71 in the kernels).  X.z null: the product has its own launch.
+struct XupdIn {
+  int n;
+  const int* __restrict__ Kp;
+  const double* __restrict__ Ksc;
+  const int* __restrict__ Kc_y;
+  const int* __restrict__ perm;
+  SaddleMaps M;
+  const double* __restrict__ b;
+  double* __restrict__ z;
+  int acc;
+  int nblocks;
+};
+__device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const double* __restrict__ ys, int m,
+                                             int* __restrict__ info) {
+  constexpr int XL = 8;  // lanes per column (columns of K hold ~10 entries in the headline configuration)
+  const int sub = threadIdx.x % XL;
+  const int cpb = ST / XL;
+  const SaddleMaps& M = X.M;
+  for (int j = xb * cpb + threadIdx.x / XL; j < X.n; j += X.nblocks * cpb) {
+    double s = 0.0;
+    const int e1 = X.Kp[j + 1];
+    for (int e = X.Kp[j] + 1 + sub; e < e1; e += XL) s += X.Ksc[e] * poll_f64(ys + X.Kc_y[e], info);
+#pragma unroll
+    for (int o = XL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, XL);
+    if (sub == 0) {
+      const int v = M.vmap ? M.vmap[j] : -1;
+      if (v >= 0) {
+        const double beta = X.b[v];
+        const double mult = (X.b[j] - beta) - s;
+        if (X.acc) {
+          X.z[j] += beta;
+          X.z[v] += mult;
+        } else {
+          X.z[j] = beta;
+          X.z[v] = mult;
+        }
+      } else if (X.acc) {
+        X.z[j] += X.b[j] - s;
+      } else {
+        X.z[j] = X.b[j] - s;
+      }
+    }
+  }
+  for (int k = xb * ST + threadIdx.x; k < m; k += X.nblocks * ST) {
+    const int i = ext_row(M, X.perm[k]);
+    if (i >= 0) {
+      const double v = poll_f64(ys + k, info) * M.dscale[k];
+      if (X.acc)
+        X.z[i] += v;
+      else
+        X.z[i] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__ items, int nf,
                                                    const double* __restrict__ SPf, const double* __restrict__ SPb,
                                                    const long long* __restrict__ xuoff,
@@ -3502,9 +3561,9 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
                                                    const int* __restrict__ rows, double* __restrict__ y,
                                                    double* __restrict__ xhat,
                                                    double* __restrict__ uvec, double* __restrict__ ysol2, int m,
-                                                   const int* __restrict__ epoch, int* __restrict__ info,
+                                                   int* __restrict__ epoch, int* __restrict__ info,
                                                    const int* __restrict__ skip, RhsIn R, DecideIn D,
-                                                   double* __restrict__ spart) {
+                                                   double* __restrict__ spart, XupdIn X) {
   __shared__ __attribute__((aligned(16))) double lds[2 * 1024 + 8];
   const int b = blockIdx.x;
   if (b == 2 * nf) {
@@ -3515,7 +3574,17 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
     return;
   }
   if (skip && *skip) return;
-  const int par = *epoch & 1;  // constant during the launch: advanced by the kernel behind it
+  const int par = *epoch & 1;  // constant while anybody reads it: advanced by the kernel behind this one, or by the
+                               // LAST workgroup of this launch (workgroups are dispatched in index order, so every
+                               // other one has read it by the time the last one is running)
+  if (b > 2 * nf) {
+    dev_x_update(X, b - 2 * nf - 1, ysol2 + (size_t)par * m, m, info);
+    if (b == (int)gridDim.x - 1) {
+      __syncthreads();
+      if (threadIdx.x == 0) *epoch += 1;
+    }
+    return;
+  }
   if (b < nf) {
     const SolveItem& T = items[b];
     dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info, R);

@@ -1030,6 +1030,7 @@ def test_deferred_refinement_verdict(fact):
     scale = [1.0, 3.0, 0.25]
     diag = kc[:-1][:20000]  # position of the unit diagonal entry of every x column (scaled values keep the saddle form)
     logs = {}
+    fact.set_option("refine_check_every", 1)  # every solve judged (the default checks every 8th once well-conditioned)
     for lazy in (1, 0):
         fact.set_option("decide_lazy", lazy)
         log = []
@@ -1052,6 +1053,75 @@ def test_deferred_refinement_verdict(fact):
         assert oa == ob and ia == ib and sa == sb
         assert sa == 0.0 and oa <= 1e-12
     fact.set_option("decide_lazy", 1)
+
+
+def test_x_update_inside_the_solve_launch(fact):
+    """The back substitution of the leaf columns (z_x = b~_x - A^^T y^, z_y = D y^) by the last workgroups of the
+    fused solve launch, polling the posted solution copy, against the separate launch behind the tree: same lanes,
+    same shuffle tree, same bits - with active bounds (working-set maps), over a sequence of right-hand sides
+    (the exchange slots alternate by launch parity, now advanced by the launch's own last workgroup) and with
+    correction passes (accumulating mode)."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 6000, 2800
+    J = synth.banded_jacobian(n, m, 12, 90, 13)
+    rng = np.random.default_rng(8)
+    vi, ci, W = _ws(n, m, rng, 0.95, 0.05)
+    rhs = [rng.standard_normal(n + W) for _ in range(7)]
+    outs = {}
+    for fused in (1, 0):
+        fact.set_option("xupd_fused", fused)
+        fact.set_option("refine_check_every", 3)
+        aug = StandardAugJac(n, fact)
+        aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+        res = []
+        for b in rhs:
+            fact.solve(b)
+            res.append(fact.solution_raw(0, n + W))
+        fact.set_option("refine_adaptive", 0)  # correction passes run unconditionally: the accumulating form
+        fact.set_option("refine_steps", 2)
+        fact.solve(rhs[0])
+        res.append(fact.solution_raw(0, n + W))
+        fact.set_option("refine_steps", 1)
+        fact.set_option("refine_adaptive", 1)
+        assert fact.info("solve_timeouts") == 0
+        outs[fused] = res
+    for a, b_ in zip(outs[1], outs[0]):
+        assert np.array_equal(a, b_)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-12
+    fact.set_option("xupd_fused", 1)
+    fact.set_option("refine_check_every", 8)
+
+
+def test_residual_checked_on_every_kth_solve_only(fact):
+    """Once a factorisation has been judged well-conditioned, the residual b - K z is taken on every k-th solve only
+    (refine_check_every, default 8; the reference's MA57 path never checks, fact_ma57.c:18): same bits as with a
+    check behind every solve, the checked ones report the same backward error, and an ill-conditioned factorisation
+    (correction passes in the graph) keeps checking every solve."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 6)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    rng = np.random.default_rng(33)
+    rhs = [rng.standard_normal(N) for _ in range(20)]
+    outs = {}
+    for every in (1, 8):
+        fact.set_option("refine_check_every", every)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        res = []
+        for b in rhs:
+            fact.solve(b)
+            res.append(fact.solution_raw(0, N))
+        outs[every] = res
+        assert fact.info("last_status") == 0.0 and fact.info("last_omega") <= 1e-12
+    for a, b_, rh in zip(outs[1], outs[8], rhs):
+        assert np.array_equal(a, b_)
+        assert scaled_residual(K, a, rh) <= 1e-12
+    fact.set_option("refine_check_every", 8)
 
 
 def test_dense_chain_levels_as_small_dataflow_launches(fact):
