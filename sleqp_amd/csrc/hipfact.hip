@@ -311,7 +311,7 @@ struct hipfact_handle : PlanState {
   long dataflow_fallbacks = 0;
   int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
-  int factor_top_max = 128;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
+  int factor_top_max = 160;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_levels = 1 << 20;  // at most this many levels in the single-launch top-of-tree factorisation (tests)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
   bool zero_behind = false;   // solve-panel items put the panels of the bottom levels back to zero (see l_prefix): -10 us on the fill, +15 us on the dataflow launch (measured), off
@@ -3366,6 +3366,14 @@ int hipfact_set_option(hipfact_handle* h, const char* name, double value) {
     h->prm.nd_sep_frac = value;
   else if (!strcmp(name, "force_generic"))
     h->prm.force_generic = value != 0.0;
+  else if (!strcmp(name, "dense_tau"))  // a Jacobian column is dense from max(dense_min, dense_tau sqrt(m)) entries
+    h->prm.dense_tau = value;
+  else if (!strcmp(name, "dense_min"))
+    h->prm.dense_min = std::max(1, (int)value);
+  else if (!strcmp(name, "dense_max"))  // at most this many (<= 64; 0: no dense-column treatment)
+    h->prm.dense_max = std::min(64, std::max(0, (int)value));
+  else if (!strcmp(name, "adopt_leaves"))
+    h->prm.adopt_leaves = value != 0.0;
   else
     plan_opt = false;
   if (plan_opt) {

@@ -679,6 +679,31 @@ class HipFactPlanStats:
         self.dense = len(p.dense_cols)
 
 
+def test_dense_column_treatment_is_an_option(fact):
+    """`dense_max = 0` sends a Jacobian with dense columns down the ordinary path (S = A A^T with the cliques in it):
+    same solution as the low-rank split, a denser factor."""
+    n, m = 900, 400
+    J0 = synth.banded_jacobian(n, m, 8, 60, 23)
+    J, _ = _with_dense_columns(J0, 2, 9)
+    rng = np.random.default_rng(2)
+    vi, ci, W = _ws(n, m, rng, 1.0, 0.0)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    b = rng.standard_normal(N)
+    sols, nnzL = [], []
+    for dmax in (64, 0):
+        fact.set_option("dense_max", dmax)
+        fact.set_matrix(N, kc, kr, kd)
+        assert fact.info("dense_columns") == (2 if dmax else 0)
+        fact.solve(b)
+        sols.append(fact.solution_raw(0, N).copy())
+        nnzL.append(fact.info("nnzL"))
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    ref.solve_dense(b)
+    z = ref.raw_solution()
+    assert rel_err(sols[0], z) <= REL_TOL and rel_err(sols[1], z) <= REL_TOL
+    assert nnzL[1] > nnzL[0]
+
+
 @pytest.mark.timeout(240)
 def test_dense_jacobian_columns_at_full_size():
     """BASELINE configs[3] (n = 1e5, m = 5e4, nnz(J) = 1e6) plus 1, 4 and 16 dense columns: the analysis no longer
