@@ -82,7 +82,7 @@ def run():
                         ("nchild", "<i4"), ("Qf", "<i4"), ("Ef", "<i4"), ("Pb", "<i4"), ("Eb", "<i4"), ("c_uoff", "<i8", 4),
                         ("c_invoff", "<i4", 4), ("Loff", "<i8"), ("xbegin", "<i4"), ("xend", "<i4"), ("a0", "<i4"), ("a1", "<i4"),
                         ("sl", "<i4"), ("nsl", "<i4"), ("poff", "<i8")])
-    raw = np.empty(nf * item_dt.itemsize, dtype=np.uint8)
+    raw = np.empty(2 * nf * item_dt.itemsize, dtype=np.uint8)  # forward order, then backward order
     lib.hipfact_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     assert lib.hipfact_debug_copy(f._h, b"sitems", raw.ctypes.data_as(C.c_void_p), raw.nbytes) == 0
     items = raw.view(item_dt)
@@ -90,7 +90,7 @@ def run():
     lev = np.array([int(P.sn_level[front_of_c0[int(c)]]) for c in items["c0"]])
     print(f"# {P.nsuper} fronts, {nf} items ({int((items['nsl'] > 1).sum())} of them row slices)")
     print("# fused solve launch, us since the first workgroup started.  per level: workgroups, entry (min..max), waited (max), posted (max)")
-    for name, sl, levels in (("forward", slice(0, nf), lev), ("backward", slice(nf, 2 * nf), lev[::-1])):
+    for name, sl, levels in (("forward", slice(0, nf), lev[:nf]), ("backward", slice(nf, 2 * nf), lev[nf:])):
         tt = t[sl]
         print(name)
         for l in (range(P.nlevels) if name == "forward" else range(P.nlevels - 1, -1, -1)):
@@ -98,6 +98,14 @@ def run():
             print(f"  level {l:2d}  fronts {int(m.sum()):4d}  entry {tt[m, 0].min():7.2f} .. {tt[m, 0].max():7.2f}  requested {tt[m, 1].max():7.2f}"
                   f"  waited {tt[m, 2].max():7.2f}  posted {tt[m, 3].max():7.2f}")
     print(f"# launch span {t[:, 3].max():.2f} us; forward done {t[:nf, 3].max():.2f}")
+    # the two bottom levels in detail: quartiles of the stamps and of the time an item stays resident
+    for name, sl, levels in (("forward", slice(0, nf), lev[:nf]), ("backward", slice(nf, 2 * nf), lev[nf:])):
+        tt = t[sl]
+        for l in (0, 1):
+            m = levels == l
+            q = lambda a: " ".join(f"{v:6.2f}" for v in np.percentile(a, [0, 25, 50, 75, 100]))
+            print(f"# {name} level {l}: entry [{q(tt[m, 0])}]  requested-entry [{q(tt[m, 1] - tt[m, 0])}]  waited-requested [{q(tt[m, 2] - tt[m, 1])}]"
+                  f"  posted-waited [{q(tt[m, 3] - tt[m, 2])}]  resident [{q(tt[m, 3] - tt[m, 0])}]  late entries (> 2 us) {int((tt[m, 0] > tt[m, 0].min() + 2).sum())}")
 
 
 if __name__ == "__main__":

@@ -259,7 +259,7 @@ struct hipfact_handle : PlanState {
   bool chain_fuse = true;         // single-front levels of a dense chain: pivot + panel items as one small dataflow launch
   bool solve_slices = true;       // fused solve: fronts whose panel share does not fit the registers of one item are row-sliced
   bool speculate = true;          // set_matrix: queue values + factorisation before the pattern comparison has finished
-  bool xupd_fused = false;       // ... and its last workgroups do the back substitution of the leaf columns (one launch per solve): measured 2 us SLOWER per solve than the separate 9 us launch (the polling loads), off
+  bool xupd_fused = true;       // ... and its last workgroups do the back substitution of the leaf columns (one launch per solve; 256 workgroups that request everything independent of y first and poll y in one batch: -4 us per solve against the separate 9 us launch)
   bool rhs_fused = true;          // fused solve: the forward items form their rows of the right-hand side themselves
   bool spanel_fold = true;        // solve panels as filler items of k_factor_top (else a launch of their own behind it)
   int spanel_fold_room = 224;     // ... as many per level as fit this many workgroup slots together with its pivot and panel items
@@ -311,6 +311,9 @@ struct hipfact_handle : PlanState {
   long dataflow_fallbacks = 0;
   int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
+  int solve_whole_max = 48;   // a front stays ONE solve item while an item thread holds at most this many panel entries (SOLVE_PREFETCH of them before its wait)
+  int xupd_blocks = 256;      // workgroups of the x update inside the tree launch (xupd_fused)
+  bool solve_sorted = true;   // solve items of a level: biggest fronts first
   int factor_top_max = 160;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
   int factor_top_levels = 1 << 20;  // at most this many levels in the single-launch top-of-tree factorisation (tests)
   int factor_top_fine = 12;   // levels with at most this many fronts use finer panel / Schur items there
@@ -701,8 +704,16 @@ static int upload_plan(hipfact_handle* h) {
     return std::max(w2 + 16, std::min({fwd, bwd, 1024}));
   };
   std::vector<int> it_front, it_sl, it_nsl, it_a0, it_a1, first_item(ns, 0);
+  // Inside a level the biggest fronts come first (both sweeps): a level with more items than CUs runs in rounds (one
+  // item per CU: its panel sits in registers), and the last round should be the cheap one.
+  std::vector<int> solve_order(P.level_sn.begin(), P.level_sn.begin() + ns);
+  if (h->solve_sorted)
+    for (int l = 0; l < P.nlevels; ++l)
+      std::stable_sort(solve_order.begin() + P.level_ptr[l], solve_order.begin() + P.level_ptr[l + 1], [&](int a, int b) {
+        return (long long)sn[a].r * sn[a].w > (long long)sn[b].r * sn[b].w;
+      });
   for (int q = 0; q < ns; ++q) {
-    const int s2 = P.level_sn[q];
+    const int s2 = solve_order[q];
     const int w2 = std::max(1, sn[s2].w), u2 = sn[s2].r - sn[s2].w;
     const int cap = slice_rows(w2);
     first_item[s2] = (int)it_front.size();
@@ -711,7 +722,7 @@ static int upload_plan(hipfact_handle* h) {
     // its wait (config 3's fronts of 600-1000 rows x 126 columns: 28 us per level); fronts a little over the register
     // capacity stay whole - a second item and the exchange of partial sums cost more than 18 loads (config 4)
     const int q1 = std::max(1, 1024 / std::max(1, sn[s2].r));
-    const bool whole = sn[s2].r <= 1024 && (w2 + q1 - 1) / q1 <= 2 * SOLVE_PREFETCH;
+    const bool whole = sn[s2].r <= 1024 && (w2 + q1 - 1) / q1 <= h->solve_whole_max;
     if (sn[s2].r <= cap || whole || !h->solve_slices) {
       cuts.push_back({0, u2});
     } else {
@@ -1136,6 +1147,23 @@ static int upload_plan(hipfact_handle* h) {
         si.push_back(T);
       }
       h->sp_lds = solve_panel_lds(wmax);
+      // items [nit, 2 nit): the backward sweep's order - levels from the root down, inside a level the same order as
+      // forward (biggest first), the slices of a front last to first (slice 0 adds the others' partial sums)
+      {
+        std::vector<int> lvl_begin(P.nlevels + 1, nit);
+        for (int q = nit - 1; q >= 0; --q) lvl_begin[P.sn_level[it_front[q]]] = q;
+        for (int l = P.nlevels - 1; l >= 0; --l)
+          if (lvl_begin[l] > lvl_begin[l + 1]) lvl_begin[l] = lvl_begin[l + 1];
+        for (int l = P.nlevels - 1; l >= 0; --l)
+          for (int q = lvl_begin[l]; q < lvl_begin[l + 1];) {
+            const int nsl = it_nsl[q];
+            for (int k = nsl - 1; k >= 0; --k) {
+              const SolveItem t = si[q + k];
+              si.push_back(t);
+            }
+            q += nsl;
+          }
+      }
       if (h->sp_lds <= 160 * 1024) {
         if ((rc = upload(h, h->d_sitems, si))) return rc;
         if ((rc = upload(h, h->d_sxuoff, xuoff))) return rc;
@@ -1575,7 +1603,7 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
         X.b = b;
         X.z = z;
         X.acc = acc ? 1 : 0;
-        X.nblocks = std::max(1, std::min(256, (P.n + 4 * (ST / 8) - 1) / (4 * (ST / 8))));
+        X.nblocks = std::max(1, std::min(h->xupd_blocks, (P.n + (ST / 8) - 1) / (ST / 8)));
         solve_m_async(h, skip, &R, &X);
         return;
       }
@@ -2070,12 +2098,15 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_TOP_PREFETCH")) h->top_prefetch = atoi(s);
   if (const char* s = getenv("HIPFACT_WIDE_MIN")) h->wide_min_rows = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_TOP")) h->factor_top_max = atoi(s);
+  if (const char* s = getenv("HIPFACT_SOLVE_SORTED")) h->solve_sorted = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_FACTOR_FINE")) h->factor_top_fine = atoi(s);
   if (const char* s = getenv("HIPFACT_FACTOR_POST")) h->factor_top_post = atoi(s);
   if (const char* s = getenv("HIPFACT_SPANEL_FOLD")) h->spanel_fold = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_ZERO_BEHIND")) h->zero_behind = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_XUPD_FUSED")) h->xupd_fused = atoi(s) != 0;
+  if (const char* s = getenv("HIPFACT_SOLVE_WHOLE_MAX")) h->solve_whole_max = std::max(SOLVE_PREFETCH, atoi(s));
+  if (const char* s = getenv("HIPFACT_XUPD_BLOCKS")) h->xupd_blocks = std::max(1, atoi(s));
   if (const char* s = getenv("HIPFACT_SOLVE_SLICES")) h->solve_slices = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_DECIDE_LAZY")) h->decide_lazy = atoi(s) != 0;

@@ -3513,39 +3513,84 @@ struct XupdIn {
 };
 __device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const double* __restrict__ ys, int m,
                                              int* __restrict__ info) {
-  constexpr int XL = 8;  // lanes per column (columns of K hold ~10 entries in the headline configuration)
+  // Same lanes per column and the same summation order as k_x_saddle (XL = 8: identical bits).  These workgroups
+  // become resident while the last backward items are still running, one per CU: everything that does not depend on
+  // y - column pointers, values, row indices of XP columns per lane group, the scales of the y part - is requested
+  // first, then all entries of y are requested in one batch and only those that still hold the sentinel are polled.
+  constexpr int XL = 8, XE = 2, XP = 4;
   const int sub = threadIdx.x % XL;
   const int cpb = ST / XL;
+  const int stride = X.nblocks * cpb;
   const SaddleMaps& M = X.M;
-  for (int j = xb * cpb + threadIdx.x / XL; j < X.n; j += X.nblocks * cpb) {
-    double s = 0.0;
-    const int e1 = X.Kp[j + 1];
-    for (int e = X.Kp[j] + 1 + sub; e < e1; e += XL) s += X.Ksc[e] * poll_f64(ys + X.Kc_y[e], info);
+  const unsigned long long* __restrict__ yb = reinterpret_cast<const unsigned long long*>(ys);
+  // the y part: z_y = D y^ (at most a few entries per thread)
+  const int k0 = xb * ST + threadIdx.x, kstride = X.nblocks * ST;
+  int yi = -1;
+  double ysc = 0.0;
+  if (k0 < m) {
+    yi = ext_row(M, X.perm[k0]);
+    ysc = M.dscale[k0];
+  }
+  for (int jb = xb * cpb + threadIdx.x / XL; jb < X.n; jb += XP * stride) {
+    double val[XP][XE];
+    int idx[XP][XE], enext[XP], eend[XP];
 #pragma unroll
-    for (int o = XL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, XL);
-    if (sub == 0) {
-      const int v = M.vmap ? M.vmap[j] : -1;
-      if (v >= 0) {
-        const double beta = X.b[v];
-        const double mult = (X.b[j] - beta) - s;
-        if (X.acc) {
-          X.z[j] += beta;
-          X.z[v] += mult;
-        } else {
-          X.z[j] = beta;
-          X.z[v] = mult;
+    for (int p = 0; p < XP; ++p) {
+      const int j = jb + p * stride;
+      const bool ok = j < X.n;
+      const int e0 = ok ? X.Kp[j] + 1 + sub : 0, e1 = ok ? X.Kp[j + 1] : 0;
+#pragma unroll
+      for (int t = 0; t < XE; ++t) {
+        const int e = e0 + XL * t;
+        val[p][t] = (e < e1) ? X.Ksc[e] : 0.0;
+        idx[p][t] = (e < e1) ? X.Kc_y[e] : -1;
+      }
+      enext[p] = e0 + XL * XE;
+      eend[p] = e1;
+    }
+    unsigned long long bits[XP][XE];
+#pragma unroll
+    for (int p = 0; p < XP; ++p)
+#pragma unroll
+      for (int t = 0; t < XE; ++t)
+        bits[p][t] = (idx[p][t] >= 0) ? __hip_atomic_load(yb + idx[p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int j = jb + p * stride;
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t < XE; ++t)
+        if (idx[p][t] >= 0) {
+          const double yv = (bits[p][t] == SOLVE_SENT) ? poll_f64(ys + idx[p][t], info) : __longlong_as_double((long long)bits[p][t]);
+          s += val[p][t] * yv;
         }
-      } else if (X.acc) {
-        X.z[j] += X.b[j] - s;
-      } else {
-        X.z[j] = X.b[j] - s;
+      for (int e = enext[p]; e < eend[p]; e += XL) s += X.Ksc[e] * poll_f64(ys + X.Kc_y[e], info);
+#pragma unroll
+      for (int o = XL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, XL);
+      if (sub == 0 && j < X.n) {
+        const int v = M.vmap ? M.vmap[j] : -1;
+        if (v >= 0) {
+          const double beta = X.b[v];
+          const double mult = (X.b[j] - beta) - s;
+          if (X.acc) {
+            X.z[j] += beta;
+            X.z[v] += mult;
+          } else {
+            X.z[j] = beta;
+            X.z[v] = mult;
+          }
+        } else if (X.acc) {
+          X.z[j] += X.b[j] - s;
+        } else {
+          X.z[j] = X.b[j] - s;
+        }
       }
     }
   }
-  for (int k = xb * ST + threadIdx.x; k < m; k += X.nblocks * ST) {
-    const int i = ext_row(M, X.perm[k]);
+  for (int k = k0; k < m; k += kstride) {
+    const int i = (k == k0) ? yi : ext_row(M, X.perm[k]);
     if (i >= 0) {
-      const double v = poll_f64(ys + k, info) * M.dscale[k];
+      const double v = poll_f64(ys + k, info) * ((k == k0) ? ysc : M.dscale[k]);
       if (X.acc)
         X.z[i] += v;
       else
@@ -3589,7 +3634,7 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
     const SolveItem& T = items[b];
     dev_solve_fwd(T, SPf, xuoff, xinvoff, inv, y, xhat, uvec, ysol2 + (size_t)(1 - par) * m, lds, info, R);
   } else {
-    const SolveItem& T = items[2 * nf - 1 - b];
+    const SolveItem& T = items[b];  // second half of the list: the backward order
     dev_solve_bwd(T, SPb, rows, y, xhat, uvec, ysol2 + (size_t)par * m, spart, lds, info);
   }
 }

@@ -682,6 +682,8 @@ class HipFactPlanStats:
 def test_dense_column_treatment_is_an_option(fact):
     """`dense_max = 0` sends a Jacobian with dense columns down the ordinary path (S = A A^T with the cliques in it):
     same solution as the low-rank split, a denser factor."""
+    from sleqp_amd.sparse import SleqpMat
+
     n, m = 900, 400
     J0 = synth.banded_jacobian(n, m, 8, 60, 23)
     J, _ = _with_dense_columns(J0, 2, 9)
@@ -692,7 +694,7 @@ def test_dense_column_treatment_is_an_option(fact):
     sols, nnzL = [], []
     for dmax in (64, 0):
         fact.set_option("dense_max", dmax)
-        fact.set_matrix(N, kc, kr, kd)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
         assert fact.info("dense_columns") == (2 if dmax else 0)
         fact.solve(b)
         sols.append(fact.solution_raw(0, N).copy())
