@@ -312,6 +312,9 @@ struct hipfact_handle : PlanState {
   int debug_phases = 15;         // timing-only phase mask of k_factor_level (15 = everything)
   int split_max_fronts = 1 << 30;  // levels with at most this many fronts use the split kernels
   int solve_whole_max = 48;   // a front stays ONE solve item while an item thread holds at most this many panel entries (SOLVE_PREFETCH of them before its wait)
+  bool cg_graph = false;      // chunks of the device-controlled CG as captured graphs (slower than direct launches here)
+  double* x_dot_out = nullptr;  // set around a projection of the device-controlled CG
+  int x_dot_blocks = 0;
   int xupd_blocks = 256;      // workgroups of the x update inside the tree launch (xupd_fused)
   bool solve_sorted = true;   // solve items of a level: biggest fronts first
   int factor_top_max = 160;   // levels with at most this many fronts join the single-launch top-of-tree factorisation (0: off)
@@ -1604,6 +1607,10 @@ static void solve_once_async(hipfact_handle* h, const double* b, double* z, bool
         X.z = z;
         X.acc = acc ? 1 : 0;
         X.nblocks = std::max(1, std::min(h->xupd_blocks, (P.n + (ST / 8) - 1) / (ST / 8)));
+        if (h->x_dot_out && !acc) {  // a CG iteration wants the partials of r.g = b_x . z_x (krylov_device.inc)
+          X.dot_out = h->x_dot_out;
+          h->x_dot_blocks = X.nblocks;
+        }
         solve_m_async(h, skip, &R, &X);
         return;
       }
@@ -2106,6 +2113,7 @@ int hipfact_create(hipfact_handle** out, int device) {
   if (const char* s = getenv("HIPFACT_RHS_FUSED")) h->rhs_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_XUPD_FUSED")) h->xupd_fused = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_SOLVE_WHOLE_MAX")) h->solve_whole_max = std::max(SOLVE_PREFETCH, atoi(s));
+  if (const char* s = getenv("HIPFACT_CG_GRAPH")) h->cg_graph = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_XUPD_BLOCKS")) h->xupd_blocks = std::max(1, atoi(s));
   if (const char* s = getenv("HIPFACT_SOLVE_SLICES")) h->solve_slices = atoi(s) != 0;
   if (const char* s = getenv("HIPFACT_CHAIN_FUSE")) h->chain_fuse = atoi(s) != 0;

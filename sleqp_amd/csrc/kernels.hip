@@ -3510,9 +3510,10 @@ struct XupdIn {
   double* __restrict__ z;
   int acc;
   int nblocks;
+  double* __restrict__ dot_out;  // per workgroup: partial of b_x . z_x (the r.g of a CG iteration), or null
 };
 __device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const double* __restrict__ ys, int m,
-                                             int* __restrict__ info) {
+                                             int* __restrict__ info, double* lds) {
   // Same lanes per column and the same summation order as k_x_saddle (XL = 8: identical bits).  These workgroups
   // become resident while the last backward items are still running, one per CU: everything that does not depend on
   // y - column pointers, values, row indices of XP columns per lane group, the scales of the y part - is requested
@@ -3526,7 +3527,7 @@ __device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const doub
   // the y part: z_y = D y^ (at most a few entries per thread)
   const int k0 = xb * ST + threadIdx.x, kstride = X.nblocks * ST;
   int yi = -1;
-  double ysc = 0.0;
+  double ysc = 0.0, dsum = 0.0;
   if (k0 < m) {
     yi = ext_row(M, X.perm[k0]);
     ysc = M.dscale[k0];
@@ -3569,9 +3570,11 @@ __device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const doub
       for (int o = XL / 2; o > 0; o >>= 1) s += __shfl_down(s, o, XL);
       if (sub == 0 && j < X.n) {
         const int v = M.vmap ? M.vmap[j] : -1;
+        const double bj = X.b[j];
         if (v >= 0) {
           const double beta = X.b[v];
-          const double mult = (X.b[j] - beta) - s;
+          const double mult = (bj - beta) - s;
+          dsum += bj * beta;
           if (X.acc) {
             X.z[j] += beta;
             X.z[v] += mult;
@@ -3580,11 +3583,23 @@ __device__ __forceinline__ void dev_x_update(const XupdIn& X, int xb, const doub
             X.z[v] = mult;
           }
         } else if (X.acc) {
-          X.z[j] += X.b[j] - s;
+          X.z[j] += bj - s;
         } else {
-          X.z[j] = X.b[j] - s;
+          const double zj = bj - s;
+          dsum += bj * zj;
+          X.z[j] = zj;
         }
       }
+    }
+  }
+  if (X.dot_out) {  // (uniform; plain assignment mode only)
+    dsum = wave_sum(dsum);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0;
+      for (int q = 0; q < ST / 64; ++q) a += lds[q];
+      X.dot_out[xb] = a;
     }
   }
   for (int k = k0; k < m; k += kstride) {
@@ -3623,7 +3638,7 @@ __global__ __launch_bounds__(ST) void k_solve_tree(const SolveItem* __restrict__
                                // LAST workgroup of this launch (workgroups are dispatched in index order, so every
                                // other one has read it by the time the last one is running)
   if (b > 2 * nf) {
-    dev_x_update(X, b - 2 * nf - 1, ysol2 + (size_t)par * m, m, info);
+    dev_x_update(X, b - 2 * nf - 1, ysol2 + (size_t)par * m, m, info, lds);
     if (b == (int)gridDim.x - 1) {
       __syncthreads();
       if (threadIdx.x == 0) *epoch += 1;

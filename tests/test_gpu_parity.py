@@ -1471,6 +1471,42 @@ def test_device_steihaug_vs_oracle(fact, radius):
     assert np.linalg.norm(step) <= radius * (1 + 1e-10)
 
 
+def test_device_controlled_cg_matches_the_host_driven_loop(fact):
+    """krylov_device.inc: the Steihaug loop with alpha, beta and the exit tests in a control block in HBM (four
+    launches per iteration, no host round trip inside a chunk) against the host-driven loop of the same handle -
+    same tests in the same order, dot products summed in another fixed order: same iteration count, iterates equal to
+    rounding; interior solution, boundary exit and negative curvature."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 3000, 1200
+    J = synth.banded_jacobian(n, m, 8, 60, 3)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.0, 1)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    B = sp.random(n, n, density=3.0 / n, random_state=3)
+    spd = sp.tril(B @ B.T + 0.5 * sp.eye(n), format="csc")
+    indef = sp.tril(B + B.T + sp.diags(np.linspace(-1.0, 2.0, n)), format="csc")
+    g = np.random.default_rng(5).standard_normal(n)
+    # (interior case: |r.g| < (1e-2 tol)^2 must stay above the rounding level of r.g, else the exit is met by chance)
+    for HL, radius, tol in ((spd, 1e3, 1e-3), (spd, 30.0, 1e-6), (indef, 2.0, 1e-6)):
+        HL.sort_indices()
+        H = SpMat(fact, SleqpMat.from_scipy(HL))
+        fact.set_option("cg_device_loop", 0)
+        want, dual0, its0 = fact.steihaug(H, g, radius, stat_tol=tol, max_iter=200)
+        fact.set_option("cg_device_loop", 1)
+        runs = fact.info("cg_device_runs")
+        step, dual1, its1 = fact.steihaug(H, g, radius, stat_tol=tol, max_iter=200)
+        assert fact.info("cg_device_runs") == runs + 1 and fact.info("cg_device_fallbacks") == 0
+        assert its1 == its0 and its0 < 200 and (HL is indef or its0 > 0), (its0, its1)
+        assert rel_err(step, want) <= 1e-10
+        assert abs(dual1 - dual0) <= 1e-9 * max(1.0, abs(dual0))
+        assert np.abs(J @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(J).sum(axis=1).max()
+        if radius < 100:
+            assert abs(np.linalg.norm(step) - radius) <= 1e-9 * radius
+        H.free()
+
+
 def test_krylov_loops_on_a_plan_with_sliced_fronts(fact):
     """Dense Schur complement (tall fronts: row-sliced items in the fused solve launch, chain levels as small
     dataflow launches) under the device-resident Krylov loops.  With H = c I the EQP step inside a large trust
