@@ -42,7 +42,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
 PROFILE_TAG = "r3"
-KERNEL_SOURCES = ("kernels.hip", "hipfact.hip", "dense_cols.inc", "vtable_superset.inc")  # hashed into the PMC files
 
 
 def make_problem(workload: str, seed: int):
@@ -231,10 +230,9 @@ def cpu_baseline(N, cp, ri, vx, b, budget_s=12.0):
 
 
 def kernels_sha():
-    h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "sleqp_amd", "csrc", name), "rb").read())
-    return h.hexdigest()[:16]
+    from sleqp_amd._lib import kernel_sources_sha16
+
+    return kernel_sources_sha16()
 
 
 def load_traffic(kernel_name, workload=None):

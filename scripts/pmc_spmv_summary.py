@@ -24,9 +24,9 @@ for op in ("J_x", "JT_y", "H_sym_x"):
     res[op] = {"calls": nf, "fetch_bytes_per_launch_raw": f, "fetch_bytes_per_launch_x2": 2 * f, "write_bytes_per_launch": w}
     print("%-10s %6d %16.0f %16.0f %16.0f" % (op, nf, f, 2 * f, w))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for name in ("kernels.hip", "hipfact.hip", "dense_cols.inc", "vtable_superset.inc"):  # = bench.py KERNEL_SOURCES
-    h.update(open(os.path.join(root, "sleqp_amd", "csrc", name), "rb").read())
-res["_kernels_sha16"] = h.hexdigest()[:16]
+sys.path.insert(0, root)
+from sleqp_amd._lib import kernel_sources_sha16  # noqa: E402
+
+res["_kernels_sha16"] = kernel_sources_sha16()
 res["_workload"] = os.environ.get("HIPFACT_PROFILE_WORKLOAD", "banded_n1e5_m5e4")  # the passes ran bench.py's default workload
 json.dump(res, open(dst, "w"), indent=1)

@@ -20,10 +20,10 @@ for k in sorted(f, key=lambda k: -f[k][1]):
     out[k] = {"calls": f[k][0], "fetch_bytes_per_launch_raw": fc * 1024, "fetch_bytes_per_launch_x2": 2 * fc * 1024, "write_bytes_per_launch": wc * 1024}
 # which kernel sources the numbers belong to (bench.py refuses to quote them for other sources)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for name in ("kernels.hip", "hipfact.hip", "dense_cols.inc", "vtable_superset.inc"):  # = bench.py KERNEL_SOURCES
-    h.update(open(os.path.join(root, "sleqp_amd", "csrc", name), "rb").read())
-out["_kernels_sha16"] = h.hexdigest()[:16]
+sys.path.insert(0, root)
+from sleqp_amd._lib import kernel_sources_sha16  # noqa: E402
+
+out["_kernels_sha16"] = kernel_sources_sha16()
 out["_workload"] = os.environ.get("HIPFACT_PROFILE_WORKLOAD", "banded_n1e5_m5e4")
 out["_note"] = "bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); fetch x2 = gfx950 correction for wide coalesced reads (upper bound)"
 json.dump(out, open(sys.argv[3], "w"), indent=1)

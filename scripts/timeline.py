@@ -66,6 +66,8 @@ def run():
 
     P = Plan(lib, N, cp, ri, vx)
     lev = P.sn_level
+    if os.environ.get("HIPFACT_TIMELINE_RAW"):
+        np.savez(os.environ["HIPFACT_TIMELINE_RAW"], tt=tt, role=role, front=front, lev=lev[front], w=np.diff(P.sn_c0)[front], r=P.sn_r[front])
     print("# per level of the dataflow launch (us): fronts, pivots waited (first..last), pivots done (last), panels published (last), Schur published (last)")
     for l in range(int(f.info("factor_top_level")), P.nlevels):
         m_ = lev[front] == l

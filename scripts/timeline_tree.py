@@ -16,10 +16,22 @@ SRC = os.path.join(ROOT, "sleqp_amd", "csrc")
 NB = 4096
 
 
+def inline_parts(path):
+    """The kernels live in kernels_*.inc files included by kernels.hip: expand them in the scratch copy, so that the
+    patches below see one text."""
+    import re
+
+    d = os.path.dirname(path)
+    text = open(path).read()
+    text = re.sub(r'^#include "(kernels_\w+\.inc)"$', lambda m: open(os.path.join(d, m.group(1))).read(), text, flags=re.M)
+    open(path, "w").write(text)
+
+
 def build():
     shutil.rmtree(SCRATCH, ignore_errors=True)
     shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
     p = os.path.join(SCRATCH, "kernels.hip")
+    inline_parts(p)
     s = open(p).read()
     s = s.replace("typedef double d4_t __attribute__((ext_vector_type(4)));",
                   f"__device__ long long g_st[{NB} * 8];\n"

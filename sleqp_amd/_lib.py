@@ -98,3 +98,17 @@ def load() -> C.CDLL:
     lib.hipfact_plan_free.restype = None
     _lib = lib
     return lib
+
+
+def kernel_sources_sha16() -> str:
+    """Hash of everything the device translation unit is compiled from (csrc/*.hip, *.inc, *.h): recorded with the
+    rocprofv3 --pmc summaries under profiles/, so that bench.py only quotes HBM traffic measured on the sources it runs."""
+    import glob
+    import hashlib
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(name).encode())
+        h.update(open(name, "rb").read())
+    return h.hexdigest()[:16]

@@ -2,7 +2,7 @@
 
 The hardware needs two wait states between a vector-ALU write of a register and its use as the
 DPP-shuffled source of a following instruction, and the compiler's hazard recogniser does not look
-into inline assembly (sleqp_amd/csrc/kernels.hip: rowb_f64 / fmac_rowb_f64 rely on the source
+into inline assembly (sleqp_amd/csrc/kernels_front_pivot.inc: rowb_f64 / fmac_rowb_f64 rely on the source
 order instead).  This test compiles the device code to assembly and checks every `*_dpp`
 instruction against the two instructions in front of it."""
 import os
