@@ -3,6 +3,7 @@
 // level schedule.  Cached per sparsity pattern (the reference's backends redo
 // their analysis on every set_matrix: fact_ma57.c:529-625, fact_cholmod.c:133,
 // fact_umfpack.c:145-160).
+#include "hostmem.h"
 #include "plan.h"
 
 #include <algorithm>
@@ -65,6 +66,30 @@ void etree(const Graph& g, const std::vector<int>& perm, const std::vector<int>&
         anc[r] = k;
         parent[r] = k;
       }
+    }
+  }
+}
+
+// The same tree for M = A A^T straight from the rows of A (Gilbert, Ng, Peyton: the column elimination tree; the
+// form of Davis' cs_etree with ata = 1): rows are visited in elimination order, and a row only has to be linked to the
+// PREVIOUS row of each of its columns - nnz(A) find-root walks instead of nnz(A A^T).  Columns flagged in `skip`
+// (dense columns, left out of M) do not link anything.
+void etree_rows(int m, int nx, const std::vector<int>& ar_ptr, const std::vector<int>& ar_col, const char* skip,
+                const std::vector<int>& perm, std::vector<int>& parent) {
+  parent.assign(m, -1);
+  std::vector<int> anc(m, -1), prev((size_t)nx, -1);
+  for (int k = 0; k < m; ++k) {
+    const int a = perm[k];
+    for (int e = ar_ptr[a]; e < ar_ptr[a + 1]; ++e) {
+      const int j = ar_col[e];
+      if (skip && skip[j]) continue;
+      for (int r = prev[j]; r != -1 && r < k;) {
+        const int nxt = anc[r];
+        anc[r] = k;
+        if (nxt == -1) parent[r] = k;
+        r = nxt;
+      }
+      prev[j] = k;
     }
   }
 }
@@ -625,7 +650,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     });
     for (int a = 0; a < m; ++a) deg[a + 1] += deg[a];
     g.ptr.assign(deg.begin(), deg.end());
-    g.adj.resize(g.ptr[m]);
+    huge_resize(g.adj, (size_t)g.ptr[m]);
     parallel_chunks(m, [&](int lo, int hi, int) {
       std::vector<int> mark(m, -1);
       for (int a = lo; a < hi; ++a) {
@@ -654,7 +679,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         }
     for (int a = 0; a < m; ++a) cnt[a + 1] += cnt[a];
     g.ptr.assign(cnt.begin(), cnt.end());
-    g.adj.resize(cnt[m]);
+    huge_resize(g.adj, (size_t)cnt[m]);
     std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
     for (int j = 0; j < N; ++j)
       for (int e = Kp[j]; e < Kp[j + 1]; ++e)
@@ -697,7 +722,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   std::vector<RawSuper> sn;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) {
-      etree(g, perm, iperm, parent);
+      if (saddle && !getenv("HIPFACT_ETREE_GRAPH"))
+        etree_rows(m, nx, ar_ptr, ar_col, is_dense.empty() ? nullptr : is_dense.data(), perm, parent);
+      else
+        etree(g, perm, iperm, parent);
       tick("  etree");
     }
     postorder(parent, pass == 0 ? nullptr : &colcount, post);
@@ -843,8 +871,8 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     }
   });
   for (int k = 0; k < m; ++k) P.Mp[k + 1] += P.Mp[k];
-  P.Mi.resize(P.Mp[m]);
-  P.Mtarget.resize(P.Mp[m]);
+  huge_resize(P.Mi, (size_t)P.Mp[m]);
+  huge_resize(P.Mtarget, (size_t)P.Mp[m]);
   {
     std::atomic<bool> bad{false};
     parallel_chunks(ns, [&](int lo, int hi, int) {
@@ -884,9 +912,15 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   // ---- value sources
   if (saddle) {
     // product lists: M(i,k) = sum_j A(perm[i], j) A(perm[k], j)
-    P.prod_ptr.assign(P.Mp[m] + 1, 0);
+    huge_resize(P.prod_ptr, (size_t)P.Mp[m] + 1);
+    if (P.Mp[m] + 1 < (int64_t)INT32_MAX)
+      parallel_chunks((int)(P.Mp[m] + 1), [&](int lo, int hi, int) {
+        std::fill(P.prod_ptr.begin() + lo, P.prod_ptr.begin() + hi, (int64_t)0);
+      });
+    else
+      std::fill(P.prod_ptr.begin(), P.prod_ptr.end(), (int64_t)0);
     // pass 0 counts, pass 1 fills; columns are independent (one pos array per thread)
-    std::vector<int64_t> fill;
+    BigVec<int64_t> fill;
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 1) {
         for (int64_t e = 0; e < P.Mp[m]; ++e) P.prod_ptr[e + 1] += P.prod_ptr[e];
@@ -895,9 +929,15 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
           P.error = "product list too large (dense column in the constraint Jacobian?)";
           return false;
         }
-        P.prod_a.resize(P.nprod);
-        P.prod_b.resize(P.nprod);
-        fill.assign(P.prod_ptr.begin(), P.prod_ptr.end() - 1);
+        huge_resize(P.prod_a, (size_t)P.nprod);
+        huge_resize(P.prod_b, (size_t)P.nprod);
+        huge_resize(fill, P.prod_ptr.size() - 1);
+        if (fill.size() < (size_t)INT32_MAX)
+          parallel_chunks((int)fill.size(), [&](int lo, int hi, int) {
+            std::copy(P.prod_ptr.begin() + lo, P.prod_ptr.begin() + hi, fill.begin() + lo);
+          });
+        else
+          std::copy(P.prod_ptr.begin(), P.prod_ptr.end() - 1, fill.begin());
       }
       parallel_chunks(m, [&](int lo, int hi, int) {
         std::vector<int> pos(m, -1);
@@ -934,7 +974,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
       std::copy(ar_col.begin() + ar_ptr[b], ar_col.begin() + ar_ptr[b + 1], P.Ar_col.begin() + P.Ar_ptr[k]);
       std::copy(ar_src.begin() + ar_ptr[b], ar_src.begin() + ar_ptr[b + 1], P.Ar_src.begin() + P.Ar_ptr[k]);
     }
-    P.Kc_y.resize(nnz);
+    huge_resize(P.Kc_y, (size_t)nnz);
     for (int j = 0; j < nx; ++j) {
       P.Kc_y[Kp[j]] = -1;
       for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) P.Kc_y[e] = iperm[Ki[e] - nx];

@@ -4,12 +4,14 @@
 #include <cstdint>
 #include <vector>
 
+#include "hostmem.h"
+
 namespace hipfact {
 
 struct Graph {
   int n = 0;
   std::vector<int64_t> ptr;  // n+1
-  std::vector<int> adj;      // ptr[n]
+  BigVec<int> adj;           // ptr[n] entries (large: huge pages, no zero fill - hostmem.h)
   int64_t nedges() const { return ptr.empty() ? 0 : ptr[n]; }
 };
 

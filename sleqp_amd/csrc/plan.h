@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include "hostmem.h"
+
 namespace hipfact {
 
 struct PlanParams {
@@ -61,13 +63,13 @@ struct Plan {
 
   // ---- M in pivot order, lower CSC (diagonal first in each column)
   std::vector<int64_t> Mp;  // m+1
-  std::vector<int> Mi;      // row indices (pivot order)
-  std::vector<int64_t> Mtarget;  // per entry: offset into the L arena
+  BigVec<int> Mi;           // row indices (pivot order)
+  BigVec<int64_t> Mtarget;  // per entry: offset into the L arena
 
   // value sources.  saddle: M[e] = sum_t Kval[prod_a[t]] * Kval[prod_b[t]],
   // t in [prod_ptr[e], prod_ptr[e+1]).  generic: M[e] = Kval[src[e]] (-1: 0).
-  std::vector<int64_t> prod_ptr;
-  std::vector<int> prod_a, prod_b;
+  BigVec<int64_t> prod_ptr;
+  BigVec<int> prod_a, prod_b;
   std::vector<int> src;
 
   // ---- supernodes (fronts)
