@@ -608,7 +608,8 @@ def main():
         ms, cnt = fact.info(f"prof_{cls}_ms"), fact.info(f"prof_{cls}_count")
         if cnt > 0:
             prof[cls] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps,
-                         "avg_launch_us": ms / cnt * 1e3}
+                         "avg_launch_us": ms / cnt * 1e3, "max_launch_us": fact.info(f"prof_{cls}_max_ms") * 1e3}
+    schur_best = (fact.info("prof_schur_best_flops"), fact.info("prof_schur_best_ms"))
     fact.set_option("profile", 0)
 
     # ---- solve-only rate (the real ratio is ~1 factor : 100 solves, trlib_solver.c:768-776)
@@ -771,9 +772,13 @@ def main():
         # the sources this run uses
         if args.workload == "banded_n1e5_m5e4":
             parts, note = [], None
-            for kname in ("k_solve_tree", "void k_x_saddle<false>", "k_residual_saddle"):
-                tr, note = load_traffic(kname, args.workload)
-                parts.append(tr)
+            tr, note = load_traffic("k_solve_tree", args.workload)
+            parts.append(tr)
+            trr, _ = load_traffic("k_residual_saddle", args.workload)  # steady state: the residual of every k-th solve only
+            parts.append(None if trr is None else trr / max(1.0, fact.info("refine_check_every")))
+            trx, _ = load_traffic("void k_x_saddle<false>", args.workload)  # (inside the tree launch when xupd_fused)
+            if trx is not None and not fact.info("xupd_fused"):
+                parts.append(trx)
             if all(v is not None for v in parts):
                 out["solve_only"]["rocprof_hbm_bytes"] = sum(parts)
                 out["solve_only"]["rocprof_hbm_GBps"] = sum(parts) / t_solve / 1e9
@@ -786,7 +791,16 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                                "flops_per_step": flops, "avg_launch_us": prof[dom]["avg_launch_us"],
-                               "note": "all factor flops attributed to the Schur kernel (upper bound)"}
+                               "note": "all factor flops attributed to the Schur kernel (upper bound); the chain's 37 "
+                                       "launches shrink with the trailing matrix, the small ones are latency-bound"}
+            # the launch that is actually bound by the matrix cores: the best Schur launch among those with at least half
+            # the flops of the largest level (the first fronts of the dense chain), its own flops over its own duration
+            if schur_best and schur_best[0] > 0 and schur_best[1] > 0:
+                fl_b, us_b = schur_best[0], schur_best[1] * 1e3
+                out["roofline"]["largest_launch"] = {"flops": fl_b, "us": us_b, "achieved": fl_b / us_b / 1e6, "unit": "TFLOP/s",
+                                                     "frac": fl_b / us_b / 1e6 / MFMA_F64_PEAK_TFLOPS,
+                                                     "note": "structural flops u (u + 1) w of one level's Schur launch over its HIP-event "
+                                                             "duration; executed flops and matrix-pipe busy share: profiles/r3_pmc_mfma_config3.txt"}
         if dom == "factorT" and fact.info("spanel_folded"):
             # the launch also builds the solve panels of EVERY front (filler workgroups between its levels): reads each
             # factor panel once more, writes both thread-major copies.  Not part of SURVEY 8(d)'s factor bytes, hence

@@ -27,3 +27,10 @@ cp $OUT/${TAG}_pmc_spmv.json $REPO/profiles/${TAG}_pmc_spmv.json
 cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/${TAG}_pmc_traffic.json
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --workload uniform_n1e4_m5e3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_config3.json 2>> $OUT/${TAG}_bench.err
+# config 3: per-kernel stats (the largest k_front_schur launch is the MFMA-bound one: MaxNs) and the matrix-pipe counters
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c3_$TAG -- python3 $REPO/bench.py --workload uniform_n1e4_m5e3 --steps 10 --warmup 2 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_c3_$TAG -- python3 $REPO/bench.py --workload uniform_n1e4_m5e3 --steps 3 --warmup 1 --no-cpu-baseline --no-ceilings --no-extras > /dev/null 2>&1
+cd $REPO
+find $OUT/prof_c3_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats_config3.csv
+python scripts/pmc_mfma_summary.py $OUT/pmc_mfma_c3_$TAG > $OUT/${TAG}_pmc_mfma_config3.txt 2>&1

@@ -34,13 +34,15 @@ while time.time() - t0 < budget:
         continue
     N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
     K = synth.kkt_full_matrix(N, kc, kr, kd)
-    opts = {"factor_top_max": int(rng.choice([128, 128, 0, 8, 400])), "pull_max_children": int(rng.choice([4, 4, 0])),
+    opts = {"factor_top_max": int(rng.choice([160, 128, 0, 8, 400])), "pull_max_children": int(rng.choice([4, 4, 0])),
             "top_max_fronts": int(rng.choice([1024, 1024, 0, 64])), "wide_min_rows": int(rng.choice([1024, 200])),
             "refine_steps": int(rng.choice([0, 1])), "use_graph": int(rng.choice([0, 1, 1])),
             "solve_fused": int(rng.choice([1, 1, 0])), "spanel_fold": int(rng.choice([1, 1, 0])),
             "spanel_fold_room": int(rng.choice([224, 16, 256])), "rhs_fused": int(rng.choice([1, 1, 0])),
             "decide_lazy": int(rng.choice([1, 1, 0])), "solve_slices": int(rng.choice([1, 1, 0])),
-            "chain_fuse": int(rng.choice([1, 1, 0])), "factor_top_levels": int(rng.choice([1 << 20, 1 << 20, 3]))}
+            "chain_fuse": int(rng.choice([1, 1, 0])), "factor_top_levels": int(rng.choice([1 << 20, 1 << 20, 3])),
+            "xupd_fused": int(rng.choice([1, 1, 0])), "refine_check_every": int(rng.choice([8, 1, 2])),
+            "superset_vtable": int(rng.choice([1, 1, 0]))}
     for k, v in opts.items():
         fact.set_option(k, v)
     try:
