@@ -1082,6 +1082,48 @@ def test_deferred_refinement_verdict(fact):
     fact.set_option("decide_lazy", 1)
 
 
+def test_solve_item_order_and_slicing_threshold(fact):
+    """The fused solve launch runs one item per CU, so a level with more items than CUs runs in rounds: items are
+    ordered biggest front first inside a level (explicit backward order behind the forward one) and a front is cut
+    into row slices once a thread would hold more than `solve_whole_max` panel entries.  Order is a permutation of
+    workgroups (same bits); slicing changes the association of the backward sums (agreement to rounding); different
+    numbers of x-update workgroups leave the bits alone."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 40000, 20000  # the headline configuration's band at 40 % of its size: fronts of ~350 rows x 128 columns
+    J = synth.banded_jacobian(n, m, 20, 200, 5)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.0, 1)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    rng = np.random.default_rng(4)
+    rhs = [rng.standard_normal(N) for _ in range(3)]
+    outs, items = {}, {}
+    for key, (srt, whole, xb) in {"default": (1, 48, 256), "plan order": (0, 48, 256), "whole": (1, 64, 256),
+                                  "sliced": (1, 32, 256), "few x blocks": (1, 48, 7)}.items():
+        fact.set_option("solve_sorted", srt)
+        fact.set_option("solve_whole_max", whole)
+        fact.set_option("xupd_blocks", xb)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        res = []
+        for b in rhs:
+            fact.solve(b)
+            res.append(fact.solution_raw(0, N))
+        assert fact.info("solve_timeouts") == 0 and fact.info("fused_solve") == 1
+        outs[key], items[key] = res, fact.info("solve_items")
+    fact.set_option("solve_sorted", 1)
+    fact.set_option("solve_whole_max", 48)
+    fact.set_option("xupd_blocks", 256)
+    assert items["sliced"] > items["default"] >= items["whole"]
+    for a, b_ in zip(outs["default"], outs["plan order"]):
+        assert np.array_equal(a, b_)
+    for a, b_ in zip(outs["default"], outs["few x blocks"]):
+        assert np.array_equal(a, b_)
+    for key in ("whole", "sliced"):
+        for a, b_ in zip(outs["default"], outs[key]):
+            assert _agree(a, b_)
+    assert scaled_residual(K, outs["sliced"][0], rhs[0]) <= 1e-12
+
+
 def test_x_update_inside_the_solve_launch(fact):
     """The back substitution of the leaf columns (z_x = b~_x - A^^T y^, z_y = D y^) by the last workgroups of the
     fused solve launch, polling the posted solution copy, against the separate launch behind the tree: same lanes,
