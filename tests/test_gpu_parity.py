@@ -1549,6 +1549,40 @@ def test_device_controlled_cg_matches_the_host_driven_loop(fact):
         H.free()
 
 
+@pytest.mark.parametrize("per_row", [1, 3, 12, 40], ids=["lanes1", "lanes4", "lanes16", "lanes64"])
+def test_device_controlled_cg_product_variants(fact, per_row):
+    """The product kernel of the device-controlled loop (B d + the partials of five dot products) exists in four
+    lane widths, chosen by the Hessian's average row length like the plain SpMV: each against the host-driven loop."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 2500, 900
+    J = synth.banded_jacobian(n, m, 8, 60, 7)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.0, 1)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    B = sp.random(n, n, density=max(per_row - 1, 0) / (2.0 * n), random_state=per_row)
+    HL = sp.tril(B + B.T + sp.diags(4.0 + 2.0 * per_row + np.arange(n) / n), format="csc")  # diagonally dominant: convex
+    HL.sort_indices()
+    assert abs(2.0 * HL.nnz / n - (per_row + 0.5)) < 0.6 * per_row + 1.0
+    g = np.random.default_rng(per_row).standard_normal(n)
+    H = SpMat(fact, SleqpMat.from_scipy(HL))
+    fact.set_option("cg_device_loop", 0)
+    want, _, its0 = fact.steihaug(H, g, 1e3, stat_tol=1e-3, max_iter=200)
+    fact.set_option("cg_device_loop", 1)
+    runs = fact.info("cg_device_runs")
+    step, _, its1 = fact.steihaug(H, g, 1e3, stat_tol=1e-3, max_iter=200)
+    assert fact.info("cg_device_runs") == runs + 1 and fact.info("cg_device_fallbacks") == 0
+    assert its1 == its0 and 0 < its0 < 200, (its0, its1)
+    assert rel_err(step, want) <= 1e-10
+    # stationarity of the projected problem: P (H step + g) = 0 up to the tolerance of the loop
+    Hs = (HL + HL.T - sp.diags(HL.diagonal())).tocsr()
+    from sleqp_amd.sparse import SleqpVec
+    pr = aug.project_nullspace(SleqpVec.from_raw(Hs @ step + g)).to_raw()
+    assert np.linalg.norm(pr) <= 1e-4 * np.linalg.norm(g)
+    H.free()
+
+
 def test_krylov_loops_on_a_plan_with_sliced_fronts(fact):
     """Dense Schur complement (tall fronts: row-sliced items in the fused solve launch, chain levels as small
     dataflow launches) under the device-resident Krylov loops.  With H = c I the EQP step inside a large trust
