@@ -38,7 +38,7 @@ def run():
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
-    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    J, N, cp, ri, vx, b = make_problem(sys.argv[2] if len(sys.argv) > 2 else "banded_n1e5_m5e4", 0)
     f = HipFact(device=0)
     f.set_option("use_graph", 0)
     for _ in range(3):
