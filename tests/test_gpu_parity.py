@@ -1541,6 +1541,11 @@ def test_device_controlled_cg_matches_the_host_driven_loop(fact):
         step, dual1, its1 = fact.steihaug(H, g, radius, stat_tol=tol, max_iter=200)
         assert fact.info("cg_device_runs") == runs + 1 and fact.info("cg_device_fallbacks") == 0
         assert its1 == its0 and its0 < 200 and (HL is indef or its0 > 0), (its0, its1)
+        # the same with the x update (and with it the partials of r.g) as launches of their own behind the tree
+        fact.set_option("xupd_fused", 0)
+        step2, _, its2 = fact.steihaug(H, g, radius, stat_tol=tol, max_iter=200)
+        fact.set_option("xupd_fused", 1)
+        assert its2 == its0 and rel_err(step2, want) <= 1e-10 and fact.info("cg_device_fallbacks") == 0
         assert rel_err(step, want) <= 1e-10
         assert abs(dual1 - dual0) <= 1e-9 * max(1.0, abs(dual0))
         assert np.abs(J @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(J).sum(axis=1).max()
