@@ -674,8 +674,18 @@ def main():
         _, _, its = fact.steihaug(Hd, grad, 1e6, stat_tol=1e-30, max_iter=20)
         t_cg = time.perf_counter() - t0
         extras["eqp_cg_device"] = {"iterations": its, "ms_per_iteration": t_cg * 1e3 / max(its, 1),
-                                   "note": "explicit Hessian in HBM: 1 projection + 1 symmetric SpMV + 3 reductions per "
-                                           "iteration, host sees 3 scalars"}
+                                   "device_runs": fact.info("cg_device_runs"), "device_fallbacks": fact.info("cg_device_fallbacks"),
+                                   "note": "explicit Hessian in HBM, loop controlled on the device: 4 launches per iteration (product + "
+                                           "dots | tests + z, r | projection with x update and r.g | beta + d), host looks at the "
+                                           "control block every 8 iterations"}
+        fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
+        t0 = time.perf_counter()
+        _, _, its = fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=20)
+        t_lzd = time.perf_counter() - t0
+        extras["eqp_lanczos_device"] = {"iterations": its, "ms_per_iteration": t_lzd * 1e3 / max(its, 1),
+                                        "note": "GLTR (what trlib runs) with the explicit Hessian in HBM: the tridiagonal "
+                                                "trust-region subproblem is solved on the host every iteration (two "
+                                                "synchronisations per iteration)"}
         Hs = (Hl + Hl.T - sp.diags(Hl.diagonal())).tocsr()
         _, _, its = fact.tr_solve(lambda d: Hs @ d, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
         t0 = time.perf_counter()
