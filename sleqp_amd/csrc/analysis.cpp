@@ -839,6 +839,53 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     Loff += ((int64_t)r * w + 1) & ~1LL;
   }
   P.L_size = Loff;
+  // Update-matrix arena with reuse.  The update matrix of a front is read by the workgroups of its PARENT only
+  // (pull extend-add), and the parent's own update matrix is written after that - so a front may take over the slot
+  // of any proper descendant two or more generations below it: everything that reads such a slot is itself a
+  // descendant of one of the front's children, which the front awaits before its first workgroup touches memory
+  // (per-level launches: kernel boundaries; dataflow launch: the children's Schur counters).  Every front hands its
+  // parent the slots of its own children plus whatever it was handed and did not use; a front takes the smallest
+  // slot that fits, or fresh memory.  A chain of fronts (dense Schur complement) ping-pongs between two slots:
+  // the arena shrinks from sum(u^2) - (m / 128) m^2 / 3 doubles for a dense S of order m - to the two largest.
+  if (prm.reuse_update_arena && !getenv("HIPFACT_U_NOREUSE")) {
+    struct Slot {
+      int64_t off, size;
+    };
+    std::vector<std::vector<Slot>> handed((size_t)ns);
+    int64_t top = 0;
+    for (int s = 0; s < ns; ++s) {  // children precede parents
+      const int64_t u = P.sn_r[s] - sn[s].w, need = (u * u + 1) & ~1LL;
+      std::vector<Slot> cand;
+      for (int ci = P.child_ptr[s]; ci < P.child_ptr[s + 1]; ++ci) {
+        std::vector<Slot>& hc = handed[(size_t)P.child_idx[ci]];
+        cand.insert(cand.end(), hc.begin(), hc.end());
+        std::vector<Slot>().swap(hc);
+      }
+      int best = -1;
+      if (need > 0)
+        for (int k = 0; k < (int)cand.size(); ++k)
+          if (cand[k].size >= need && (best < 0 || cand[k].size < cand[best].size)) best = k;
+      if (need == 0) {
+        P.sn_Uoff[s] = 0;
+      } else if (best >= 0) {
+        P.sn_Uoff[s] = cand[best].off;
+        cand.erase(cand.begin() + best);
+      } else {
+        P.sn_Uoff[s] = top;
+        top += need;
+      }
+      for (int ci = P.child_ptr[s]; ci < P.child_ptr[s + 1]; ++ci) {
+        const int c = P.child_idx[ci];
+        const int64_t uc = P.sn_r[c] - sn[c].w, sz = (uc * uc + 1) & ~1LL;
+        if (sz > 0) cand.push_back({P.sn_Uoff[c], sz});
+      }
+      // (a handful of the largest is all an ancestor can use)
+      std::sort(cand.begin(), cand.end(), [](const Slot& a, const Slot& b) { return a.size > b.size; });
+      if (cand.size() > 8) cand.resize(8);
+      handed[(size_t)s] = std::move(cand);
+    }
+    P.U_size = top;
+  }
   // relative indices: position of each below-row in the parent's front
   P.rel.resize(P.rel_ptr[ns]);
   for (int s = 0; s < ns; ++s) {

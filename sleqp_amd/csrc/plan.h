@@ -43,6 +43,7 @@ struct PlanParams {
   double dense_tau = 4.0;
   int dense_min = 64;
   int dense_max = 64;
+  bool reuse_update_arena = true;  // a front may take over the update-matrix slot of a descendant two generations down
   bool adopt_leaves = true;   // childless fronts that are not adjacent to their parent are renumbered and merged into it
   bool force_generic = false;
 };
