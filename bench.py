@@ -53,6 +53,8 @@ def make_problem(workload: str, seed: int):
         J = synth.banded_jacobian(10000, 5000, 20, 200, seed)
     elif workload == "uniform_n1e4_m5e3":
         J = synth.uniform_jacobian(10000, 5000, 10, seed)
+    elif workload == "uniform_n1e5_m5e4":  # SURVEY 8(d) config 4b (optional stress): dense Schur complement, ~3.6e13 flops
+        J = synth.uniform_jacobian(100000, 50000, 20, seed)
     elif workload == "tiny":
         J = synth.banded_jacobian(400, 200, 8, 60, seed)
     else:
@@ -801,8 +803,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                                "flops_per_step": flops, "avg_launch_us": prof[dom]["avg_launch_us"],
-                               "note": "all factor flops attributed to the Schur kernel (upper bound); the chain's 37 "
-                                       "launches shrink with the trailing matrix, the small ones are latency-bound"}
+                               "note": "all factor flops attributed to the Schur kernel (upper bound); the launches of the "
+                                       "dense chain shrink with the trailing matrix, the small ones are latency-bound"}
             # the launch that is actually bound by the matrix cores: the best Schur launch among those with at least half
             # the flops of the largest level (the first fronts of the dense chain), its own flops over its own duration
             if schur_best and schur_best[0] > 0 and schur_best[1] > 0:
@@ -810,7 +812,8 @@ def main():
                 out["roofline"]["largest_launch"] = {"flops": fl_b, "us": us_b, "achieved": fl_b / us_b / 1e6, "unit": "TFLOP/s",
                                                      "frac": fl_b / us_b / 1e6 / MFMA_F64_PEAK_TFLOPS,
                                                      "note": "structural flops u (u + 1) w of one level's Schur launch over its HIP-event "
-                                                             "duration; executed flops and matrix-pipe busy share: profiles/r3_pmc_mfma_config3.txt"}
+                                                             "duration (config 3: executed flops and matrix-pipe busy share in "
+                                                             "profiles/r3_pmc_mfma_config3.txt)"}
         if dom == "factorT" and fact.info("spanel_folded"):
             # the launch also builds the solve panels of EVERY front (filler workgroups between its levels): reads each
             # factor panel once more, writes both thread-major copies.  Not part of SURVEY 8(d)'s factor bytes, hence

@@ -861,6 +861,19 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         cand.insert(cand.end(), hc.begin(), hc.end());
         std::vector<Slot>().swap(hc);
       }
+      // neighbours in memory become one slot (siblings were carved out of fresh memory side by side: a parent whose
+      // update matrix is bigger than any of its grandchildren's still fits into several of them together)
+      std::sort(cand.begin(), cand.end(), [](const Slot& a, const Slot& b) { return a.off < b.off; });
+      {
+        size_t o = 0;
+        for (size_t k = 0; k < cand.size(); ++k) {
+          if (o > 0 && cand[o - 1].off + cand[o - 1].size == cand[k].off)
+            cand[o - 1].size += cand[k].size;
+          else
+            cand[o++] = cand[k];
+        }
+        cand.resize(o);
+      }
       int best = -1;
       if (need > 0)
         for (int k = 0; k < (int)cand.size(); ++k)
@@ -869,7 +882,9 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         P.sn_Uoff[s] = 0;
       } else if (best >= 0) {
         P.sn_Uoff[s] = cand[best].off;
-        cand.erase(cand.begin() + best);
+        cand[best].off += need;  // the rest of the slot stays available
+        cand[best].size -= need;
+        if (cand[best].size == 0) cand.erase(cand.begin() + best);
       } else {
         P.sn_Uoff[s] = top;
         top += need;

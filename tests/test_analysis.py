@@ -44,6 +44,40 @@ def _structure_invariants(P):
     order = np.argsort(P.sn_Loff)
     ends = P.sn_Loff[order] + P.sn_r[order].astype(np.int64) * w[order]
     assert np.all(ends[:-1] <= P.sn_Loff[order][1:]) and (ns == 0 or ends[-1] <= P.L_size)
+    _update_arena_invariants(P)
+
+
+def _update_arena_invariants(P):
+    """Update matrices share memory (analysis.cpp: a front may take over the slot of a descendant two or more
+    generations below it).  Two slots may therefore overlap only when one front is such a descendant of the other;
+    in particular a front never overlaps its children (it reads them while it writes its own), its parent, its
+    siblings or anything in another subtree (which may run at the same time in the dataflow launch)."""
+    ns = P.nsuper
+    w = np.diff(P.sn_c0).astype(np.int64)
+    u = P.sn_r.astype(np.int64) - w
+    size = u * u
+    lo, hi = P.sn_Uoff.astype(np.int64), P.sn_Uoff.astype(np.int64) + size
+    assert np.all(lo >= 0) and np.all(hi[size > 0] <= P.U_size)
+    idx = [s for s in range(ns) if size[s] > 0]
+    idx.sort(key=lambda s: lo[s])
+    depth = np.zeros(ns, dtype=np.int64)
+    for s in range(ns - 1, -1, -1):  # parents have higher indices
+        if P.sn_parent[s] >= 0:
+            depth[s] = depth[P.sn_parent[s]] + 1
+
+    def generations_above(a, b):  # b is the k-th ancestor of a -> k, else -1
+        k, x = 0, a
+        while x >= 0 and depth[x] > depth[b]:
+            x, k = P.sn_parent[x], k + 1
+        return k if x == b else -1
+
+    active = []  # sweep over the slots in address order
+    for s in idx:
+        active = [t for t in active if hi[t] > lo[s]]
+        for t in active:
+            k = generations_above(s, t) if depth[s] > depth[t] else generations_above(t, s)
+            assert k >= 2, (s, t, k)
+        active.append(s)
 
 
 @pytest.mark.parametrize("n,m,kind,frac", [(2, 1, "u", 0.0), (4, 2, "u", 0.5), (40, 20, "b", 0.0), (40, 20, "u", 0.2),
@@ -55,6 +89,25 @@ def test_saddle_plan(hipfact_lib, n, m, kind, frac):
     P = _check(hipfact_lib, N, cp, ri, vx)
     assert P.saddle and P.n == n and P.m == N - n
     _structure_invariants(P)
+
+
+def test_update_arena_is_reused_along_a_dense_chain(hipfact_lib):
+    """Uniform Jacobian: A A^T fills in completely and the upper part of the tree is a chain of 128-column fronts over a
+    dense trailing matrix.  Without reuse the update matrices add up to ~ (m / 128) m^2 / 3 doubles; a chain
+    ping-pongs between two slots, so the arena is a small multiple of the largest one."""
+    n, m = 6000, 3000
+    J = synth.uniform_jacobian(n, m, 10, 3)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    P = Plan(hipfact_lib, N, cp, ri, vx)
+    _structure_invariants(P)
+    w = np.diff(P.sn_c0).astype(np.int64)
+    u = P.sn_r.astype(np.int64) - w
+    assert P.U_size < 0.6 * float((u * u).sum())  # (the bushy part below the chain keeps its siblings alive side by side)
+    assert P.U_size <= 10 * int((u * u).max())
+    b = np.random.default_rng(0).standard_normal(N)
+    z = EmulFactor(P, vx).solve(b)
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    assert np.abs(K @ z - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
 
 
 def test_identity_only(hipfact_lib):

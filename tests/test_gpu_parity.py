@@ -1082,6 +1082,39 @@ def test_deferred_refinement_verdict(fact):
     fact.set_option("decide_lazy", 1)
 
 
+def test_dense_chain_above_the_bushy_part_of_the_tree(fact):
+    """SURVEY 8(d) config 4b in small: 20 nonzeros per row at uniform columns - A A^T fills in completely and the
+    chain of 128-column fronts over the dense trailing matrix sits ABOVE the front that joins the subtrees.  Those
+    levels have thousands of Schur tiles per front: they must not join the dataflow launch (at config 4b's size that
+    would be 10^8 workgroups - the launch is refused) but run pivot + panel as the small dataflow launch and the Schur
+    update at three workgroups per CU; the update matrices share memory along the chain."""
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 16000, 8000
+    J = synth.uniform_jacobian(n, m, 20, 0)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    assert fact.info("nlevels") > 40 and fact.info("fused_solve") == 1
+    # the launch holds the top of the chain only (fronts of up to 1024 update rows: 8 levels of <= 128 columns)
+    assert fact.info("factor_top_count") < 40000
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        b = rng.standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert scaled_residual(K, z, b) <= 1e-12
+    assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
+    # linearity at this size: K (z1 + 2 z2) = b1 + 2 b2
+    b1, b2 = rng.standard_normal(N), rng.standard_normal(N)
+    fact.solve(b1)
+    z1 = fact.solution_raw(0, N).copy()
+    fact.solve(b2)
+    z2 = fact.solution_raw(0, N).copy()
+    fact.solve(b1 + 2.0 * b2)
+    assert rel_err(fact.solution_raw(0, N), z1 + 2.0 * z2) <= 1e-9
+
+
 def test_solve_item_order_and_slicing_threshold(fact):
     """The fused solve launch runs one item per CU, so a level with more items than CUs runs in rounds: items are
     ordered biggest front first inside a level (explicit backward order behind the forward one) and a front is cut
