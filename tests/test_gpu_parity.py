@@ -1450,6 +1450,51 @@ def test_full_size_properties(fact, workload):
     assert np.abs(A @ x - rhs[n:]).max() <= 1e-9 * max(1.0, np.abs(x).max()) * np.abs(A).sum(axis=1).max()
 
 
+def test_full_size_krylov_loops(fact):
+    """BASELINE.json configs[3] (n = 1e5, m = 5e4) under the device-resident Krylov loops of the EQP step, with the
+    banded Hessian of the bench: the device-controlled CG against the host-driven loop (iteration count, step), the
+    generalised Lanczos method against CG inside a large trust region (same minimiser of the projected model), the
+    step in the null space of the working-set rows, the model decrease, the boundary case on the boundary."""
+    from bench import make_problem
+    from sleqp_amd.fact import SpMat
+    from sleqp_amd.sparse import SleqpMat
+
+    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    m, n = J.shape
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    rng = np.random.default_rng(7)
+    # (the Hessian of bench.py's spmv_setup: symmetric banded, half-bandwidth 5, diagonally dominant)
+    Hl = sp.diags([np.full(n, 2.0)] + [rng.standard_normal(n - k) * 0.1 for k in range(1, 6)], [0, -1, -2, -3, -4, -5], format="csc")
+    Hl.sort_indices()
+    Hd = SpMat(fact, SleqpMat(n, n, Hl.indptr, Hl.indices, Hl.data))
+    Hs = (Hl + Hl.T - sp.diags(Hl.diagonal())).tocsr()
+    g = rng.standard_normal(n)
+    A = J.tocsr()
+    anorm = np.abs(A).sum(axis=1).max()
+    fact.set_option("cg_device_loop", 0)
+    want, _, its0 = fact.steihaug(Hd, g, 1e6, stat_tol=1e-3, max_iter=300)
+    fact.set_option("cg_device_loop", 1)
+    runs = fact.info("cg_device_runs")
+    step, _, its1 = fact.steihaug(Hd, g, 1e6, stat_tol=1e-3, max_iter=300)
+    assert fact.info("cg_device_runs") == runs + 1 and fact.info("cg_device_fallbacks") == 0
+    assert 0 < its0 < 300 and its1 == its0
+    assert rel_err(step, want) <= 1e-9
+    assert np.abs(A @ step).max() <= 1e-9 * anorm * max(1.0, np.abs(step).max())
+    q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
+    assert q(step) < 0.0
+    lz, _, its2 = fact.tr_solve(Hd, g, 1e6, method=1, stat_tol=1e-3, max_iter=300)
+    # (both stop at stat_tol 1e-3 by their own tests: the iterates agree to that order, the model values much better)
+    assert 0 < its2 < 300 and rel_err(lz, step) <= 2e-4 and abs(q(lz) - q(step)) <= 1e-7 * abs(q(step))
+    # trust region active
+    radius = 0.3 * np.linalg.norm(step)
+    for method in (0, 1):
+        sb, dual, _ = fact.tr_solve(Hd, g, radius, method=method, stat_tol=1e-6, max_iter=300)
+        assert abs(np.linalg.norm(sb) - radius) <= 1e-8 * radius and dual >= 0.0
+        assert np.abs(A @ sb).max() <= 1e-9 * anorm * max(1.0, np.abs(sb).max())
+        assert q(sb) < 0.0
+    Hd.free()
+
+
 def test_adaptive_refinement_and_graphs(fact):
     """Refinement runs only when the residual asks for it; graph replay and direct launches agree bitwise."""
     from sleqp_amd.sparse import SleqpMat
