@@ -48,6 +48,14 @@ struct FrontItem {
   PullDesc pd;
 };
 
+// k_front_schur_pair: the second front b of a pair of chain fronts forms its update matrix from the grandchild's
+// (U_g, leading dimension u_g, entry (i, j) of U_b at (i + off_g, j + off_g)) with the panels of a (its child) and b
+struct PairDesc {
+  long long Loff_a, Uoff_g;
+  int w_a, r_a, rowoff_a;  // rows of L21_a that belong to U_b's rows start at rowoff_a (= w_b)
+  int u_g, off_g;
+};
+
 // one workgroup of the single-launch top-of-tree factorisation kernel
 struct TopFItem {
   FrontItem it;

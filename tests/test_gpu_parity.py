@@ -1105,6 +1105,17 @@ def test_dense_chain_above_the_bushy_part_of_the_tree(fact):
         z = fact.solution_raw(0, N)
         assert scaled_residual(K, z, b) <= 1e-12
     assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
+    # the chain is updated two fronts at a time (k_front_schur_pair: the second front's update matrix straight from
+    # the grandchild's with both panels - half the trailing-matrix traffic); one front at a time agrees to rounding
+    assert fact.info("chain_pairs") >= 10
+    fact.set_option("chain_pairs", 0)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    assert fact.info("chain_pairs") == 0
+    fact.solve(b)
+    z1f = fact.solution_raw(0, N)
+    assert scaled_residual(K, z1f, b) <= 1e-12 and _agree(z1f, z)
+    fact.set_option("chain_pairs", 1)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
     # linearity at this size: K (z1 + 2 z2) = b1 + 2 b2
     b1, b2 = rng.standard_normal(N), rng.standard_normal(N)
     fact.solve(b1)
