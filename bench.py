@@ -211,7 +211,22 @@ def cpu_baseline(N, cp, ri, vx, b, budget_s=12.0):
             list(ex.map(lambda _: [one() for _ in range(per)], range(cores)))
         dt = time.perf_counter() - t0
         out["all_cores"] = {"value": cores * per / dt, "unit": "factor+solve/s", "cores": cores,
-                            "sample": f"{cores} threads x {per} x the same unit, independent instances"}
+                            "kind": "independent instances",
+                            "sample": f"{cores} threads x {per} x the same unit: {cores} INDEPENDENT instances of the 1-thread port "
+                                      "(thread_test.c:77-110), not one K on all cores - for that see `pardiso.all_cores`"}
+    # MKL PARDISO (mtype -2): the multithreaded supernodal symmetric-indefinite solver that IS in the image, as the
+    # stand-in for the reference's MA57 / UMFPACK path (oracle/pardiso_baseline.py; bench infrastructure only)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pardiso_baseline
+
+        out["pardiso"] = pardiso_baseline.baseline_subprocess(N, cp, ri, vx, b, budget_s=min(budget_s, 8.0))
+        pn = out["pardiso"].get("all_cores", {}).get("numeric_only")
+        if pn:
+            out["pardiso_numeric_only"] = {"value": pn["value"], "unit": "factor+solve/s", "cores": out["pardiso"]["all_cores"]["cores"],
+                                           "sample": "PARDISO phase 22 + 33 per unit, analysis kept (the like-for-like of the GPU `value`)"}
+    except Exception as e:  # noqa: BLE001
+        out["pardiso"] = {"present": False, "error": repr(e)[:200]}
     # scipy SuperLU anchor (SURVEY.md §6 probe: 3.94 s factor / 33.5 ms solve in the survey container)
     try:
         import scipy.sparse.linalg as spla
@@ -383,13 +398,50 @@ def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     for _ in range(steps):
         solve_only()
     t_solve = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert shim.sleqp_fact_set_matrix(fact, K) == 0
+    t_set = (time.perf_counter() - t0) / steps
     nnz = int(cp[N])
     out = {"rate": 1.0 / t_unit, "unit": "factor+solve/s", "ms_per_unit": t_unit * 1e3,
-           "cold_first_call_s": t_cold, "solve_plus_solution_ms": t_solve * 1e3,
-           "pcie_bytes_per_unit": {"up_set_matrix": 8 * nnz, "up_rhs": 12 * N, "down_solution": 8 * n},
+           "cold_first_call_s": t_cold, "solve_plus_solution_ms": t_solve * 1e3, "set_matrix_ms": t_set * 1e3,
+           "pcie_bytes_per_unit": {"up_set_matrix": 8 * nnz, "up_rhs": 8 * N, "down_solution": 8 * N},
            "note": "through shim/fact_hipfact.c (the five SleqpFact callbacks): pattern compare on the host (beside the factorisation, which is queued first), "
-                   "values, rhs and solution copied from / to the caller's arrays by the copy engine, zero-pivot check (D2H + sync), sparse rhs upload + scatter, "
-                   "solve, refinement verdict, solution(0, n) D2H and sleqp_vec_set_from_raw on the host"}
+                   "K's values copied from the caller's array by the copy engine, zero-pivot check (D2H + sync); the right-hand side through a pinned "
+                   "staging buffer of the handle (one memcpy; a contiguous run of indices needs no index upload and no scatter), solve, refinement "
+                   "verdict, the whole solution sent to pinned memory behind the solve, ONE event wait in solution(0, n), sleqp_vec_set_from_raw "
+                   "straight out of the pinned buffer"}
+    # where solve + solution spend their time (option boundary_profile of the library: host clock around the staging
+    # memcpy / the queueing / the wait, HIP events around the right-hand-side kernel / the solve / the download)
+    try:
+        lib = C.CDLL(os.path.join(ROOT, "sleqp_amd", "csrc", "libhipfact.so"))
+        shim.sleqp_fact_hipfact_last_handle.restype = C.c_void_p
+        hh = C.c_void_p(shim.sleqp_fact_hipfact_last_handle())
+        lib.hipfact_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        lib.hipfact_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        if hh.value and lib.hipfact_set_option(hh, b"boundary_profile", 1.0) == 0:
+            for _ in range(steps):
+                solve_only()
+            def info(key):
+                v = C.c_double()
+                assert lib.hipfact_get_info(hh, key.encode(), C.byref(v)) == 0
+                return v.value
+            cnt = max(info("bd_count"), 1.0)
+            bd = {"h2d_stage_memcpy": info("bd_stage_us") / cnt, "queue_api_calls": info("bd_queue_us") / cnt,
+                  "h2d_rhs_kernel": info("bd_rhs_us") / cnt, "device_solve": info("bd_device_us") / cnt,
+                  "d2h": info("bd_d2h_us") / cnt, "wait_host": info("bd_wait_us") / cnt,
+                  "verdict_and_view": info("bd_copyout_us") / cnt, "samples": int(cnt)}
+            lib.hipfact_set_option(hh, b"boundary_profile", 0.0)
+            raw = np.ascontiguousarray(np.random.default_rng(5).standard_normal(n))
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                shim.sleqp_vec_set_from_raw(sol, raw.ctypes.data_as(C.c_void_p), n, zero_eps)
+            bd["set_from_raw"] = (time.perf_counter() - t0) / steps * 1e6
+            bd["note"] = ("us per solve + solution; device_solve / h2d_rhs_kernel / d2h are HIP-event spans on the stream (they overlap "
+                          "queue_api_calls and are what wait_host waits for), the others are host time")
+            out["breakdown_us"] = bd
+    except Exception as e:  # noqa: BLE001
+        out["breakdown_us"] = {"error": repr(e)}
     shim.sleqp_vec_free(C.byref(rhs))
     shim.sleqp_vec_free(C.byref(sol))
     shim.sleqp_mat_release(C.byref(K))

@@ -92,6 +92,17 @@ int hipfact_solve_dense(hipfact_handle* h, const double* rhs);
  * different ranges (standard_aug_jac.c:337-338 vs :382-386). */
 int hipfact_solution(hipfact_handle* h, double* out, int begin, int end);
 
+/* The same without the copy: *view points at entries [begin, end) of the last
+ * solution in page-locked host memory owned by the handle (valid until the
+ * next solve / set_matrix on this handle).  Every reference backend keeps the
+ * dense solution in a buffer of its own and sparsifies straight out of it
+ * (sleqp_vec_set_from_raw(sol, ma57_data->rhs_sol + begin, ...),
+ * fact_ma57.c:713-730; fact_cholmod.c:211-228; fact_umfpack.c:245-262); this
+ * entry point gives the shim that buffer.  The solve entry points above queue
+ * the transfer of the whole solution behind the solve, so this call waits for
+ * one event and touches no device API otherwise. */
+int hipfact_solution_view(hipfact_handle* h, const double** view, int begin, int end);
+
 /* Replaces SLEQP_FACT_CONDITION (fact/fact_types.h:20-21; the callback may be
  * NULL in the reference, fact.c:104-118).  Returns the pivot-ratio estimate
  * max|d| / min|d| of the block-diagonal factor, like CHOLMOD's rcond-based

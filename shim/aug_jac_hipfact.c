@@ -47,7 +47,6 @@ typedef struct AugJacData
 
   int* var_index;  /* num_variables */
   int* cons_index; /* num_constraints */
-  double* slice;   /* dense staging for hipfact_solution */
 } AugJacData;
 
 #define HIPFACT_CALL(data, x)                                                  \
@@ -138,9 +137,13 @@ solve_and_extract(AugJacData* jacobian, const SleqpVec* rhs, int total_size, Sle
 {
   HIPFACT_CALL(jacobian, hipfact_solve_sparse(jacobian->handle, total_size, rhs->nnz, rhs->indices, rhs->data));
 
-  HIPFACT_CALL(jacobian, hipfact_solution(jacobian->handle, jacobian->slice, begin, end));
+  /* the dense solution stays in page-locked memory of the backend (sent there
+   * behind the solve); sparsified straight out of it like fact_ma57.c:713-730 */
+  const double* slice = NULL;
 
-  SLEQP_CALL(sleqp_vec_set_from_raw(sol, jacobian->slice, end - begin, jacobian->zero_eps));
+  HIPFACT_CALL(jacobian, hipfact_solution_view(jacobian->handle, &slice, begin, end));
+
+  SLEQP_CALL(sleqp_vec_set_from_raw(sol, slice, end - begin, jacobian->zero_eps));
 
   return SLEQP_OKAY;
 }
@@ -213,7 +216,6 @@ aug_jac_free(void* data)
 
   hipfact_free(&jacobian->handle);
 
-  sleqp_free(&jacobian->slice);
   sleqp_free(&jacobian->prev_cons_index);
   sleqp_free(&jacobian->prev_var_index);
   sleqp_free(&jacobian->cons_index);
@@ -262,8 +264,6 @@ sleqp_hipfact_aug_jac_create(SleqpAugJac** star,
   if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->cons_index, num_constraints));
   if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->prev_var_index, num_variables));
   if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->prev_cons_index, num_constraints));
-  /* |W| <= n (pub_working_set.h:12-13): n doubles cover both solution slices */
-  if (status == SLEQP_OKAY) status = (sleqp_alloc_array(&jacobian->slice, 2 * num_variables + num_constraints));
 
   int hipfact_status = HIPFACT_OK;
 

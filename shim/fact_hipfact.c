@@ -43,10 +43,6 @@ typedef struct
 {
   hipfact_handle* handle;
 
-  /* dense staging buffer for hipfact_solution -> sleqp_vec_set_from_raw */
-  double* slice;
-  int slice_size;
-
   int num_rows;
 
   /* counters of the handle at the last look (debug log of what a call cost) */
@@ -161,12 +157,6 @@ hipfact_fact_set_matrix(void* fact_data, SleqpMat* matrix)
 
   assert(num_cols == num_rows);
 
-  if (data->slice_size < num_rows)
-  {
-    SLEQP_CALL(sleqp_realloc(&data->slice, num_rows));
-    data->slice_size = num_rows;
-  }
-
   data->num_rows = num_rows;
 
   /* uploads K (or only its values when the pattern is unchanged) and runs the
@@ -211,11 +201,16 @@ hipfact_fact_solution(void* fact_data,
 
   assert(begin <= end);
 
-  HIPFACT_CALL(data, hipfact_solution(data->handle, data->slice, begin, end));
+  /* the dense solution stays in (page-locked) memory of the backend, like
+   * ma57_data->rhs_sol (fact_ma57.c:713-730); it was sent there behind the
+   * solve, this call waits for that transfer */
+  const double* slice = NULL;
+
+  HIPFACT_CALL(data, hipfact_solution_view(data->handle, &slice, begin, end));
 
   hipfact_log_events(data, "solution");
 
-  SLEQP_CALL(sleqp_vec_set_from_raw(sol, data->slice, end - begin, zero_eps));
+  SLEQP_CALL(sleqp_vec_set_from_raw(sol, slice, end - begin, zero_eps));
 
   return SLEQP_OKAY;
 }
@@ -248,8 +243,6 @@ hipfact_fact_free(void** star)
 #endif
 
   hipfact_free(&data->handle);
-
-  sleqp_free(&data->slice);
 
   sleqp_free(&data);
 
@@ -334,8 +327,24 @@ sleqp_fact_hipfact_psd_create(SleqpFact** star, SleqpSettings* settings)
   data->psd = true;
 
   /* never the saddle interpretation, whatever the pattern looks like */
-  HIPFACT_CALL(data, hipfact_set_option(data->handle, "force_generic", 1.));
-  HIPFACT_CALL(data, hipfact_set_option(data->handle, "superset_vtable", 0.));
+  {
+    int status = hipfact_set_option(data->handle, "force_generic", 1.);
+
+    if (status == HIPFACT_OK)
+    {
+      status = hipfact_set_option(data->handle, "superset_vtable", 0.);
+    }
+
+    if (status != HIPFACT_OK)
+    {
+      /* nothing owns the backend data yet: release it before raising */
+      void* fact_data = (void*)data;
+      SLEQP_CALL(hipfact_fact_free(&fact_data));
+      sleqp_raise(SLEQP_INTERNAL_ERROR,
+                  "Failed to configure the hipfact PSD backend <%d>",
+                  status);
+    }
+  }
 
   SLEQP_CALL(sleqp_fact_create(star,
                                SLEQP_FACT_HIPFACT_NAME "-psd",

@@ -26,7 +26,7 @@ ERRORS = {
 # every symbol include/hipfact.h declares
 SYMBOLS = [
     "hipfact_create", "hipfact_free", "hipfact_retain", "hipfact_last_error", "hipfact_set_matrix", "hipfact_solve_sparse",
-    "hipfact_solve_dense", "hipfact_solution", "hipfact_condition", "hipfact_refactor_device",
+    "hipfact_solve_dense", "hipfact_solution", "hipfact_solution_view", "hipfact_condition", "hipfact_refactor_device",
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_check", "hipfact_stream",
     "hipfact_assemble_kkt", "hipfact_reduced_matrix", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
     "hipfact_spmat_mult_vec", "hipfact_spmat_mult_vec_trans", "hipfact_spmat_mult_vec_sym",
@@ -63,6 +63,7 @@ def load() -> C.CDLL:
     lib.hipfact_solve_sparse.argtypes = [vp, ci, ci, vp, vp]
     lib.hipfact_solve_dense.argtypes = [vp, vp]
     lib.hipfact_solution.argtypes = [vp, vp, ci, ci]
+    lib.hipfact_solution_view.argtypes = [vp, C.POINTER(vp), ci, ci]
     lib.hipfact_condition.argtypes = [vp, C.POINTER(cd)]
     lib.hipfact_refactor_device.argtypes = [vp, vp]
     lib.hipfact_solve_device.argtypes = [vp, vp, vp]

@@ -1602,6 +1602,120 @@ def test_device_steihaug_vs_oracle(fact, radius):
     assert np.linalg.norm(step) <= radius * (1 + 1e-10)
 
 
+@pytest.mark.parametrize("method", [0, 1], ids=["steihaug", "gltr"])
+def test_krylov_loops_with_dense_jacobian_columns(fact, method):
+    """Dense Jacobian columns under the device Krylov loops: the projection is then K_0^-1 b plus
+    a correction, and the partial dot products the x update of the tree launch leaves belong to the UNCORRECTED solve -
+    the loops must form r.g / ||t||_P^2 from the corrected z.  Projected CG against the oracle's CG (iterates and
+    iteration count), GLTR against the same minimiser; device-controlled and host-driven loop alike."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 1500, 700
+    J, dcols = _with_dense_columns(synth.banded_jacobian(n, m, 10, 80, 17), 3, 5)
+    rng = np.random.default_rng(9)
+    vi, ci, W = _ws(n, m, rng, 1.0, 0.0)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    assert fact.info("dense_columns") + fact.info("late_columns") == 3
+    B = sp.random(n, n, density=3.0 / n, random_state=3)
+    HL = sp.tril(B @ B.T + 0.5 * sp.eye(n), format="csc")
+    HL.sort_indices()
+    H = SpMat(fact, SleqpMat.from_scipy(HL))
+    g = rng.standard_normal(n)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    for radius, tol in ((1e3, 1e-4), (3.0, 1e-6)):
+        want, its_ref = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g,
+                                                                  trust_radius=radius, stat_tol=tol)
+        assert 0 < its_ref < 100
+        for device_loop in (1, 0):
+            fact.set_option("cg_device_loop", device_loop)
+            step, dual, its = fact.tr_solve(H, g, radius, method=method, stat_tol=tol, max_iter=200)
+            if method == 0:
+                assert abs(its - its_ref) <= 1, (its, its_ref)
+            assert rel_err(step, want) <= (1e-6 if radius > 100 else 1e-7), (radius, device_loop)
+            assert np.abs(J @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(J).sum(axis=1).max()
+            assert np.linalg.norm(step) <= radius * (1 + 1e-10)
+    H.free()
+
+
+def test_host_boundary_fast_path(fact):
+    """The host boundary of the unmodified vtable (sleqp_fact_solve / sleqp_fact_solution): pinned staging, a right-hand
+    side that is one contiguous run of indices without index upload or scatter, the whole solution sent to pinned
+    memory behind the solve and read through hipfact_solution / hipfact_solution_view.  Every variant (kernel-read or
+    copy-engine upload, copy-engine or kernel download, the round-3 path) must give the SAME bits, for run-shaped,
+    scattered, empty and single-entry right-hand sides, several solution ranges per solve and two solves in a row
+    without a solution in between; out-of-range indices are refused."""
+    import ctypes as C
+
+    from sleqp_amd import _lib
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    n, m = 1500, 700
+    J, vi, ci, W = _problem(n, m, "b", 0.05, 3)
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    ref = oracle.OracleFact(N, kc, kr, kd)
+    rng = np.random.default_rng(8)
+    cases = []
+    cases.append(("dense", np.arange(N, dtype=np.int32), rng.standard_normal(N)))
+    cases.append(("prefix_run", np.arange(n, dtype=np.int32), rng.standard_normal(n)))           # project / lsq: dense g
+    cases.append(("shifted_run", np.arange(n, N, dtype=np.int32), rng.standard_normal(N - n)))   # min-norm: dense c
+    idx = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32)
+    cases.append(("scattered", idx, rng.standard_normal(idx.size)))
+    cases.append(("single", np.array([N // 2], dtype=np.int32), np.array([1.5])))
+    cases.append(("empty", np.zeros(0, dtype=np.int32), np.zeros(0)))
+    lib = _lib.load()
+    variants = [dict(boundary_fast=1, boundary_h2d=0, boundary_d2h=0), dict(boundary_fast=1, boundary_h2d=1, boundary_d2h=1),
+                dict(boundary_fast=1, boundary_h2d=0, boundary_d2h=0, validate_rhs=1), dict(boundary_fast=0)]
+    for name, ix, vals in cases:
+        ref.solve_sparse(ix, vals)
+        want = ref.raw_solution()
+        got = []
+        for opts in variants:
+            for k, v in opts.items():
+                fact.set_option(k, v)
+            fact.solve(SleqpVec(N, ix, vals))
+            parts = [fact.solution_raw(0, n).copy(), fact.solution_raw(n, N).copy(), fact.solution_raw(5, 17).copy()]
+            z = np.concatenate(parts[:2])
+            assert np.array_equal(z[5:17], parts[2])
+            view = C.c_void_p()
+            assert lib.hipfact_solution_view(fact._h, C.byref(view), n, N) == 0
+            zv = np.ctypeslib.as_array(C.cast(view, C.POINTER(C.c_double)), shape=(N - n,)).copy()
+            assert np.array_equal(zv, parts[1]), name
+            got.append(z)
+            fact.set_option("validate_rhs", 0)
+        for z in got[1:]:
+            assert np.array_equal(z, got[0]), name
+        assert rel_err(got[0], want) <= REL_TOL or np.abs(want).max() == 0.0, name
+    fact.set_option("boundary_fast", 1)
+    # two solves without a solution in between: the second one's result is what solution() returns
+    b1, b2 = rng.standard_normal(N), rng.standard_normal(N)
+    fact.solve(b1)
+    fact.solve(b2)
+    ref.solve_dense(b2)
+    assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL
+    # many solves in a row (both staging buffers, the unchecked steady state, every 8th solve checked)
+    for t in range(20):
+        bt = rng.standard_normal(N)
+        fact.solve(SleqpVec(N, np.arange(N, dtype=np.int32), bt))
+        ref.solve_dense(bt)
+        assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL, t
+    # indices outside [0, N): refused on the host when they are the first / last one, ignored by the device otherwise
+    from sleqp_amd._lib import HipfactError
+
+    for bad in (np.array([0, N], dtype=np.int32), np.array([-1, 3], dtype=np.int32)):
+        with pytest.raises(HipfactError):
+            fact.solve(SleqpVec(N, bad, np.ones(2)))
+    fact.set_option("validate_rhs", 1)
+    with pytest.raises(HipfactError):  # not ascending: only the full walk sees it
+        fact.solve(SleqpVec(N, np.array([4, 2, 9], dtype=np.int32), np.ones(3)))
+    fact.set_option("validate_rhs", 0)
+    fact.solve(b1)  # the handle is still usable
+    ref.solve_dense(b1)
+    assert rel_err(fact.solution_raw(0, N), ref.raw_solution()) <= REL_TOL
+
+
 def test_device_controlled_cg_matches_the_host_driven_loop(fact):
     """krylov_device.inc: the Steihaug loop with alpha, beta and the exit tests in a control block in HBM (four
     launches per iteration, no host round trip inside a chunk) against the host-driven loop of the same handle -
