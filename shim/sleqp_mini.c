@@ -213,19 +213,34 @@ sleqp_vec_resize(SleqpVec* vec, int dim)
   return SLEQP_OKAY;
 }
 
+/* Two passes like vec.c:71-103 (count, reserve, push).  The pushes of the
+ * second pass cannot fail - capacity was reserved for exactly these entries,
+ * indices ascend by construction -, and the reference's sleqp_vec_push checks
+ * them with assert only (vec.c:45-69: compiled out of a release build), so the
+ * stores are done in place here. */
 SLEQP_RETCODE
 sleqp_vec_set_from_raw(SleqpVec* vec, const double* values, int dim, double zero_eps)
 {
   int nnz = 0;
   for (int i = 0; i < dim; ++i)
-    if (!(fabs(values[i]) <= zero_eps))
-      ++nnz;
+    nnz += !(fabs(values[i]) <= zero_eps);
   SLEQP_CALL(sleqp_vec_clear(vec));
   SLEQP_CALL(sleqp_vec_resize(vec, dim));
   SLEQP_CALL(sleqp_vec_reserve(vec, nnz));
+  double* data = vec->data;
+  int* indices = vec->indices;
+  int k        = 0;
   for (int i = 0; i < dim; ++i)
-    if (!(fabs(values[i]) <= zero_eps))
-      SLEQP_CALL(sleqp_vec_push(vec, i, values[i]));
+  {
+    const double v = values[i];
+    if (!(fabs(v) <= zero_eps))
+    {
+      data[k]    = v;
+      indices[k] = i;
+      ++k;
+    }
+  }
+  vec->nnz = k;
   return SLEQP_OKAY;
 }
 
