@@ -508,6 +508,11 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   if (const char* e = getenv("HIPFACT_MAX_CHILDREN")) prm.max_children = atoi(e);
   if (const char* e = getenv("HIPFACT_ADOPT")) prm.adopt_leaves = atoi(e) != 0;
   if (const char* e = getenv("HIPFACT_DENSE_TAU")) prm.dense_tau = atof(e);
+  if (const char* e = getenv("HIPFACT_DENSE_MODE")) prm.dense_mode = atoi(e);
+  if (const char* e = getenv("HIPFACT_LATE_TAU")) prm.late_tau = atof(e);
+  if (const char* e = getenv("HIPFACT_LATE_MAX")) prm.late_max = atoi(e);
+  if (const char* e = getenv("HIPFACT_HUB_TAU")) prm.hub_tau = atof(e);
+  if (const char* e = getenv("HIPFACT_PROD_BUDGET")) prm.prod_budget = atof(e);
   if (const char* e = getenv("HIPFACT_ND_SEP_FRAC")) prm.nd_sep_frac = atof(e);
   if (const char* e = getenv("HIPFACT_RELAX")) {
     double a, b, c;
@@ -566,13 +571,15 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   P.saddle = saddle;
   P.n = saddle ? n : 0;
   P.m = saddle ? N - n : N;
-  const int m = P.m;
+  const int my = P.m;  // constraint rows (saddle) / order of the matrix (generic)
   const int nx = P.n;
+  P.my = saddle ? my : 0;
 
-  // ---- dense columns of A: left out of S (their rows would form cliques); handled by the solves
+  // ---- dense columns of A
+  // mode 2 (low-rank correction, dense_cols.inc): left out of S (their rows would form cliques); handled by the solves
   std::vector<char> is_dense;
-  if (saddle && prm.dense_tau > 0.0 && prm.dense_max > 0 && m > 0) {
-    const double thr = std::max((double)prm.dense_min, prm.dense_tau * std::sqrt((double)m));
+  if (saddle && prm.dense_mode == 2 && prm.dense_tau > 0.0 && prm.dense_max > 0 && my > 0) {
+    const double thr = std::max((double)prm.dense_min, prm.dense_tau * std::sqrt((double)my));
     std::vector<std::pair<int, int>> cand;  // (-count, column)
     for (int j = 0; j < nx; ++j) {
       const int c = Kp[j + 1] - Kp[j] - 1;
@@ -589,19 +596,70 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
       std::sort(P.dense_cols.begin(), P.dense_cols.end());
     }
   }
-  const char* dn = is_dense.empty() ? nullptr : is_dense.data();
-  // ---- graph of M (saddle: S = A A^T, generic: K + K^T), no diagonal
+  // mode 1 (late elimination): the variable stays a vertex of the graph, ordered behind the constraint rows.  Chosen
+  // by count (the clique c^2 / 2 against the at most m entries of a late row of L) and by the budget of the product
+  // lists (sum over the ordinary columns of c (c + 1) / 2 pairs).
+  std::vector<int> late_of;  // per x column: index of its late vertex, -1 = ordinary
+  int k_late = 0;
+  if (saddle && prm.dense_mode == 1 && my > 0) {
+    const double thr = std::max((double)prm.late_min, prm.late_tau * std::sqrt((double)my));
+    const int cap = prm.late_max > 0 ? prm.late_max : std::max(64, my / 4);
+    double pairs = 0.0;
+    std::vector<std::pair<int, int>> cand;  // (-count, column): everything that could matter for the budget
+    for (int j = 0; j < nx; ++j) {
+      const int c = Kp[j + 1] - Kp[j] - 1;
+      pairs += 0.5 * (double)c * (c + 1);
+      if (c >= 16) cand.push_back({-c, j});
+    }
+    std::sort(cand.begin(), cand.end());
+    for (const auto& cj : cand) {
+      const int c = -cj.first;
+      if (k_late >= cap || !((double)c > thr || pairs > prm.prod_budget)) break;
+      if (late_of.empty()) late_of.assign((size_t)nx, -1);
+      late_of[(size_t)cj.second] = 0;  // (numbered below, in column order)
+      pairs -= 0.5 * (double)c * (c + 1);
+      ++k_late;
+    }
+    if (k_late > 0) {
+      int t = 0;
+      for (int j = 0; j < nx; ++j)
+        if (late_of[(size_t)j] >= 0) {
+          late_of[(size_t)j] = t++;
+          P.late_cols.push_back(j);
+        }
+    }
+    if (pairs > 2.0e9) {
+      P.error = "product list too large (the constraint Jacobian has too many dense columns for S = A A^T)";
+      return false;
+    }
+  }
+  P.n_late = k_late;
+  const int m = my + k_late;  // order of M
+  P.m = m;
+  // columns that do not enter the products of S = A_s A_s^T (either mode)
+  std::vector<char> skipcol;
+  if (!is_dense.empty())
+    skipcol = is_dense;
+  else if (k_late > 0) {
+    skipcol.assign((size_t)nx, 0);
+    for (int j : P.late_cols) skipcol[(size_t)j] = 1;
+  }
+  const char* dn = skipcol.empty() ? nullptr : skipcol.data();
+  const int* lateof = late_of.empty() ? nullptr : late_of.data();
+  // ---- graph of M (saddle: S = A_s A_s^T plus the late variables' rows, generic: K + K^T), no diagonal
   Graph g;
   g.n = m;
   g.ptr.assign(m + 1, 0);
   std::vector<int> ar_ptr, ar_col, ar_src;  // CSR of A in original row order
+  std::vector<char> late_row;               // constraint rows ordered behind the late variables
+  int n_late_rows = 0;
   if (saddle) {
-    ar_ptr.assign(m + 1, 0);
+    ar_ptr.assign(my + 1, 0);
     for (int j = 0; j < nx; ++j)
       for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) ++ar_ptr[Ki[e] - nx + 1];
-    for (int a = 0; a < m; ++a) ar_ptr[a + 1] += ar_ptr[a];
-    ar_col.resize(ar_ptr[m]);
-    ar_src.resize(ar_ptr[m]);
+    for (int a = 0; a < my; ++a) ar_ptr[a + 1] += ar_ptr[a];
+    ar_col.resize(ar_ptr[my]);
+    ar_src.resize(ar_ptr[my]);
     std::vector<int> fill(ar_ptr.begin(), ar_ptr.end() - 1);
     for (int j = 0; j < nx; ++j)
       for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
@@ -613,28 +671,52 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     // A row whose ONLY entry lies in a dense column (the unit row of an active bound on that variable, when K's own
     // pattern is analysed) would vanish from A_s: that column stays an ordinary one (x_j is pinned by the row)
     if (!is_dense.empty()) {
+      // (mode 2; ADVICE round 3: not only singleton rows - every row has to keep an entry outside the dense columns,
+      // or S_s gets a zero row although K is regular)
       bool changed = false;
-      for (int a = 0; a < m; ++a)
-        if (ar_ptr[a + 1] - ar_ptr[a] == 1 && is_dense[(size_t)ar_col[ar_ptr[a]]]) {
+      for (int a = 0; a < my; ++a) {
+        bool has_ordinary = ar_ptr[a + 1] == ar_ptr[a];
+        for (int q = ar_ptr[a]; q < ar_ptr[a + 1] && !has_ordinary; ++q) has_ordinary = !is_dense[(size_t)ar_col[q]];
+        if (!has_ordinary) {
           is_dense[(size_t)ar_col[ar_ptr[a]]] = 0;
           changed = true;
         }
+      }
       if (changed) {
         P.dense_cols.clear();
         for (int j = 0; j < nx; ++j)
           if (is_dense[(size_t)j]) P.dense_cols.push_back(j);
+        skipcol = is_dense;
+        dn = skipcol.data();
       }
     }
-    // S = A A^T: rows are independent (count, prefix, fill; one marker array per thread)
+    // mode 1: such a row is ordered BEHIND the late variables instead (its pivot then is the positive
+    // sum of a_id^2 / |d_d| and more; in front of them it would be an exact zero)
+    if (k_late > 0) {
+      late_row.assign((size_t)my, 0);
+      for (int a = 0; a < my; ++a) {
+        bool has_ordinary = ar_ptr[a + 1] == ar_ptr[a];
+        for (int q = ar_ptr[a]; q < ar_ptr[a + 1] && !has_ordinary; ++q) has_ordinary = !skipcol[(size_t)ar_col[q]];
+        if (!has_ordinary) {
+          late_row[(size_t)a] = 1;
+          ++n_late_rows;
+        }
+      }
+    }
+    // rows are independent (count, prefix, fill; one marker array per thread).  Row a < my: the rows that share an
+    // ordinary column with it and the late variables among its columns; vertex my + t: the rows of late column t.
     std::vector<int64_t> deg(m + 1, 0);
-    parallel_chunks(m, [&](int lo, int hi, int) {
-      std::vector<int> mark(m, -1);
+    parallel_chunks(my, [&](int lo, int hi, int) {
+      std::vector<int> mark(my, -1);
       for (int a = lo; a < hi; ++a) {
         mark[a] = a;
         int64_t c = 0;
         for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
           const int j = ar_col[q];
-          if (dn && dn[j]) continue;
+          if (dn && dn[j]) {
+            if (lateof && lateof[j] >= 0) ++c;
+            continue;
+          }
           for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
             const int b = Ki[e] - nx;
             if (mark[b] != a) {
@@ -646,17 +728,21 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         deg[a + 1] = c;
       }
     });
+    for (int t = 0; t < k_late; ++t) deg[my + t + 1] = Kp[P.late_cols[(size_t)t] + 1] - Kp[P.late_cols[(size_t)t]] - 1;
     for (int a = 0; a < m; ++a) deg[a + 1] += deg[a];
     g.ptr.assign(deg.begin(), deg.end());
     huge_resize(g.adj, (size_t)g.ptr[m]);
-    parallel_chunks(m, [&](int lo, int hi, int) {
-      std::vector<int> mark(m, -1);
+    parallel_chunks(my, [&](int lo, int hi, int) {
+      std::vector<int> mark(my, -1);
       for (int a = lo; a < hi; ++a) {
         mark[a] = a;
         int64_t o = g.ptr[a];
         for (int q = ar_ptr[a]; q < ar_ptr[a + 1]; ++q) {
           const int j = ar_col[q];
-          if (dn && dn[j]) continue;
+          if (dn && dn[j]) {
+            if (lateof && lateof[j] >= 0) g.adj[o++] = my + lateof[j];
+            continue;
+          }
           for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
             const int b = Ki[e] - nx;
             if (mark[b] != a) {
@@ -667,6 +753,27 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         }
       }
     });
+    for (int t = 0; t < k_late; ++t) {
+      const int d = P.late_cols[(size_t)t];
+      int64_t o = g.ptr[my + t];
+      for (int e = Kp[d] + 1; e < Kp[d + 1]; ++e) g.adj[o++] = Ki[e] - nx;
+    }
+    // hub rows: adjacent to a large share of all rows - out of the dissection, ordered last
+    if (prm.hub_tau > 0.0 && prm.ordering != 2) {
+      const double thr = std::max((double)prm.hub_min, prm.hub_tau * std::sqrt((double)my));
+      int nh = 0;
+      for (int a = 0; a < my; ++a) nh += (double)(g.ptr[a + 1] - g.ptr[a]) > thr;
+      // (a graph in which every other row qualifies is simply dense: nothing to take out)
+      if (nh > 0 && nh <= std::max(64, my / 16)) {
+        if (late_row.empty()) late_row.assign((size_t)my, 0);
+        for (int a = 0; a < my; ++a)
+          if ((double)(g.ptr[a + 1] - g.ptr[a]) > thr && !late_row[(size_t)a]) {
+            late_row[(size_t)a] = 1;
+            ++n_late_rows;
+          }
+      }
+    }
+    if (n_late_rows == 0) late_row.clear();
   } else {
     std::vector<int64_t> cnt(m + 1, 0);
     for (int j = 0; j < N; ++j)
@@ -686,27 +793,74 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
           g.adj[fill[Ki[e]]++] = j;
         }
   }
+  P.n_late_rows = n_late_rows;
 
   tick("validate + graph of M");
   // ---- ordering
   const double t1 = now_s();
   std::vector<int> perm;
-  if (prm.ordering == 2) {
-    perm.resize(m);
-    std::iota(perm.begin(), perm.end(), 0);
-  } else if (prm.ordering == 1) {
-    amd_order(g, perm);
+  auto order_graph = [&](const Graph& gg, std::vector<int>& pp) {
+    if (prm.ordering == 2) {
+      pp.resize((size_t)gg.n);
+      std::iota(pp.begin(), pp.end(), 0);
+    } else if (prm.ordering == 1) {
+      amd_order(gg, pp);
+    } else {
+      NDParams nd;
+      nd.max_sep_frac = prm.nd_sep_frac;
+      if (prm.nd_leaf > 0)
+        nd.leaf_size = prm.nd_leaf;
+      else
+        nd.leaf_size = std::max(prm.wmax, 32);  // a leaf subgraph that fits one front is not dissected further
+      if (const char* e = getenv("HIPFACT_ND_SMALL_SEP_FRAC")) nd.small_sep_frac = atof(e);
+      if (const char* e = getenv("HIPFACT_ND_REFINE")) nd.refine = atoi(e) != 0;
+      if (const char* e = getenv("HIPFACT_ND_BALANCE")) nd.balance = atof(e);
+      nd_order(gg, nd, pp);
+    }
+  };
+  if (k_late == 0 && n_late_rows == 0) {
+    order_graph(g, perm);
   } else {
-    NDParams nd;
-    nd.max_sep_frac = prm.nd_sep_frac;
-    if (prm.nd_leaf > 0)
-      nd.leaf_size = prm.nd_leaf;
-    else
-      nd.leaf_size = std::max(prm.wmax, 32);  // a leaf subgraph that fits one front is not dissected further
-    if (const char* e = getenv("HIPFACT_ND_SMALL_SEP_FRAC")) nd.small_sep_frac = atof(e);
-    if (const char* e = getenv("HIPFACT_ND_REFINE")) nd.refine = atoi(e) != 0;
-    if (const char* e = getenv("HIPFACT_ND_BALANCE")) nd.balance = atof(e);
-    nd_order(g, nd, perm);
+    // the ordinary rows are ordered on their own graph; behind them the late variables, then the late rows
+    std::vector<int> newid((size_t)m, -1), oldid;
+    oldid.reserve((size_t)my);
+    for (int a = 0; a < my; ++a)
+      if (late_row.empty() || !late_row[(size_t)a]) {
+        newid[(size_t)a] = (int)oldid.size();
+        oldid.push_back(a);
+      }
+    const int mr = (int)oldid.size();
+    Graph gr;
+    gr.n = mr;
+    gr.ptr.assign((size_t)mr + 1, 0);
+    parallel_chunks(mr, [&](int lo, int hi, int) {
+      for (int r = lo; r < hi; ++r) {
+        const int a = oldid[(size_t)r];
+        int64_t c = 0;
+        for (int64_t q = g.ptr[a]; q < g.ptr[a + 1]; ++q) c += newid[(size_t)g.adj[q]] >= 0;
+        gr.ptr[(size_t)r + 1] = c;
+      }
+    });
+    for (int r = 0; r < mr; ++r) gr.ptr[(size_t)r + 1] += gr.ptr[(size_t)r];
+    huge_resize(gr.adj, (size_t)gr.ptr[(size_t)mr]);
+    parallel_chunks(mr, [&](int lo, int hi, int) {
+      for (int r = lo; r < hi; ++r) {
+        const int a = oldid[(size_t)r];
+        int64_t o = gr.ptr[(size_t)r];
+        for (int64_t q = g.ptr[a]; q < g.ptr[a + 1]; ++q) {
+          const int b = newid[(size_t)g.adj[q]];
+          if (b >= 0) gr.adj[o++] = b;
+        }
+      }
+    });
+    std::vector<int> pr;
+    order_graph(gr, pr);
+    perm.resize((size_t)m);
+    int k = 0;
+    for (int r = 0; r < mr; ++r) perm[(size_t)k++] = oldid[(size_t)pr[(size_t)r]];
+    for (int t = 0; t < k_late; ++t) perm[(size_t)k++] = my + t;
+    for (int a = 0; a < my; ++a)
+      if (!late_row.empty() && late_row[(size_t)a]) perm[(size_t)k++] = a;
   }
   std::vector<int> iperm(m);
   for (int k = 0; k < m; ++k) iperm[perm[k]] = k;
@@ -720,8 +874,8 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   std::vector<RawSuper> sn;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) {
-      if (saddle && !getenv("HIPFACT_ETREE_GRAPH"))
-        etree_rows(m, nx, ar_ptr, ar_col, is_dense.empty() ? nullptr : is_dense.data(), perm, parent);
+      if (saddle && k_late == 0 && !getenv("HIPFACT_ETREE_GRAPH"))
+        etree_rows(m, nx, ar_ptr, ar_col, dn, perm, parent);
       else
         etree(g, perm, iperm, parent);
       tick("  etree");
@@ -1013,9 +1167,35 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         for (int k = lo; k < hi; ++k) {
           for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) pos[P.Mi[e]] = (int)(e - P.Mp[k]);
           const int b = perm[k];
+          auto one_pair = [&](int i, int ea, int eb) {  // a single product: an entry between a row and a late variable
+            const int64_t me = P.Mp[k] + pos[i];
+            if (pass == 0)
+              ++P.prod_ptr[me + 1];
+            else {
+              P.prod_a[fill[me]] = ea;
+              P.prod_b[fill[me]] = eb;
+              ++fill[me];
+            }
+          };
+          if (b >= my) {
+            // late variable x_d (its diagonal has no product: the numeric phase sets it to -1): the entries
+            // a^_id = K(e) * 1 (the unit diagonal of column d) towards the rows of its column ordered behind it
+            const int d = P.late_cols[(size_t)(b - my)];
+            for (int e = Kp[d] + 1; e < Kp[d + 1]; ++e) {
+              const int i = iperm[Ki[e] - nx];
+              if (i > k) one_pair(i, e, Kp[d]);
+            }
+            continue;
+          }
           for (int q = ar_ptr[b]; q < ar_ptr[b + 1]; ++q) {
             const int j = ar_col[q];
-            if (dn && dn[j]) continue;
+            if (dn && dn[j]) {
+              if (lateof && lateof[j] >= 0) {  // ... and towards the late variables ordered behind this row
+                const int i = iperm[my + lateof[j]];
+                if (i > k) one_pair(i, ar_src[q], Kp[j]);
+              }
+              continue;
+            }
             const int eb = ar_src[q];
             for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
               const int i = iperm[Ki[e] - nx];
@@ -1034,12 +1214,21 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
       });
     }
     // SpMV structures
+    // (the row of a late variable x_d in this CSR: its own unit entry, so that the right-hand side of its
+    // equation -x_d' + A_d^T y = b_d is b_d)
     P.Ar_ptr.assign(m + 1, 0);
-    for (int k = 0; k < m; ++k) P.Ar_ptr[k + 1] = P.Ar_ptr[k] + (ar_ptr[perm[k] + 1] - ar_ptr[perm[k]]);
+    for (int k = 0; k < m; ++k)
+      P.Ar_ptr[k + 1] = P.Ar_ptr[k] + (perm[k] < my ? ar_ptr[perm[k] + 1] - ar_ptr[perm[k]] : 1);
     P.Ar_col.resize(P.Ar_ptr[m]);
     P.Ar_src.resize(P.Ar_ptr[m]);
     for (int k = 0; k < m; ++k) {
       const int b = perm[k];
+      if (b >= my) {
+        const int d = P.late_cols[(size_t)(b - my)];
+        P.Ar_col[P.Ar_ptr[k]] = d;
+        P.Ar_src[P.Ar_ptr[k]] = Kp[d];
+        continue;
+      }
       std::copy(ar_col.begin() + ar_ptr[b], ar_col.begin() + ar_ptr[b + 1], P.Ar_col.begin() + P.Ar_ptr[k]);
       std::copy(ar_src.begin() + ar_ptr[b], ar_src.begin() + ar_ptr[b + 1], P.Ar_src.begin() + P.Ar_ptr[k]);
     }

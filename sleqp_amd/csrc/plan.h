@@ -43,6 +43,30 @@ struct PlanParams {
   double dense_tau = 4.0;
   int dense_min = 64;
   int dense_max = 64;
+  // How such columns are treated.
+  //   1 (default)  LATE ELIMINATION inside the tree: x_d is not eliminated with the other leaf columns; it stays a
+  //                vertex of the graph that is ordered behind every ordinary constraint row, i.e. the engine factors
+  //                the symmetric quasi-definite matrix  M = [ A_s A_s^T  A_d ; A_d^T  -I ]  (y first: the pivots of
+  //                the late variables are the negated capacitance matrix I + A_d^T S_s^-1 A_d, negative by inertia).
+  //                What an ordering on K itself does with a dense column (AMD's dense-row rule behind MA57,
+  //                fact_ma57.c:314-345, 761-763) - any number of columns, no extra solves per factorisation.
+  //   2            the low-rank correction of round 3 (dense_cols.inc: at most 64 columns, k solves per factorisation)
+  //   0            off: the cliques go into S
+  int dense_mode = 1;
+  // mode 1: a column is late from max(late_min, late_tau sqrt(m)) entries (its clique in S, c^2 / 2 entries, then
+  // outweighs the at most m entries its late row of L can get), the densest late_max of them at most (0: automatic,
+  // max(64, m / 4)); and whatever the counts, columns go late - densest first - until the product lists of S hold at
+  // most prod_budget pairs (sum of c (c + 1) / 2 over the ordinary columns: the analysis never spends seconds building
+  // lists before it notices that the pattern needs another strategy)
+  double late_tau = 1.5;
+  int late_min = 48;
+  int late_max = 0;
+  double prod_budget = 2.5e8;
+  // Hub rows: constraint rows with more than max(hub_min, hub_tau sqrt(m)) neighbours in the graph of S (a budget-type
+  // constraint that touches every variable is adjacent to every other row: no vertex separator exists around it) are
+  // taken out of the graph the nested dissection sees and ordered last, like AMD's dense rows.  0 = off.
+  double hub_tau = 10.0;
+  int hub_min = 256;
   bool reuse_update_arena = true;  // a front may take over the update-matrix slot of a descendant two generations down
   bool adopt_leaves = true;   // childless fronts that are not adjacent to their parent are renumbered and merged into it
   bool force_generic = false;
@@ -52,7 +76,10 @@ struct Plan {
   // ---- problem
   int N = 0;  // dimension of K
   int n = 0;  // saddle: number of x columns; generic: 0
-  int m = 0;  // order of M (saddle: constraints, generic: N)
+  int m = 0;  // order of M (saddle: constraint rows + late variables, generic: N)
+  int my = 0;      // saddle: constraint rows (= N - n); vertices my .. m-1 of M are the late variables
+  int n_late = 0;  // late variables (dense_mode 1): M = [A_s A_s^T  A_d; A_d^T  -I], exactly n_late negative pivots
+  int n_late_rows = 0;  // constraint rows ordered behind the late variables (hub rows, rows without an ordinary entry)
   bool saddle = false;
   bool saddle_shape = false;  // the STRUCTURE is [I A^T; A 0] (saddle = structure and unit diagonal values)
   int n_shape = 0;            // ... with this many x columns
@@ -96,7 +123,8 @@ struct Plan {
   std::vector<int> Ar_col;   // column (x index)
   std::vector<int> Ar_src;   // index into Kval
   std::vector<int> Kc_y;     // per K entry in columns < n: pivot position of its y row, -1 for the diagonal
-  std::vector<int> dense_cols;  // x columns left out of S = A A^T (ascending); see PlanParams::dense_tau
+  std::vector<int> dense_cols;  // x columns left out of S = A A^T (ascending); see PlanParams::dense_tau (dense_mode 2)
+  std::vector<int> late_cols;   // dense_mode 1: late variable t (vertex my + t of M) is x column late_cols[t] (ascending)
 
   // ---- statistics
   int64_t nnzL = 0;       // entries of L incl. diagonal (M part, dense panels)

@@ -54,7 +54,7 @@ int hipfact_plan_array(const hipfact_plan* plan, const char* name, const void** 
   ARR(Kp) ARR(Ki) ARR(perm) ARR(iperm) ARR(Mp) ARR(Mi) ARR(Mtarget) ARR(prod_ptr) ARR(prod_a) ARR(prod_b) ARR(src)
   ARR(sn_c0) ARR(sn_r) ARR(sn_rowptr) ARR(sn_rows) ARR(sn_parent) ARR(sn_level) ARR(sn_Loff) ARR(sn_Uoff)
   ARR(sn_uoff) ARR(child_ptr) ARR(child_idx) ARR(rel_ptr) ARR(rel) ARR(level_ptr) ARR(level_sn) ARR(Ar_ptr)
-  ARR(Ar_col) ARR(Ar_src) ARR(Kc_y) ARR(dense_cols)
+  ARR(Ar_col) ARR(Ar_src) ARR(Kc_y) ARR(dense_cols) ARR(late_cols)
 #undef ARR
   return HIPFACT_EINVAL;
 }
@@ -67,7 +67,7 @@ int hipfact_plan_scalar(const hipfact_plan* plan, const char* name, double* valu
     *value = (double)P.field;   \
     return HIPFACT_OK;          \
   }
-  SC(N) SC(n) SC(m) SC(saddle) SC(nnzK) SC(nsuper) SC(nlevels) SC(L_size) SC(U_size) SC(u_size) SC(nnzL)
+  SC(N) SC(n) SC(m) SC(my) SC(n_late) SC(n_late_rows) SC(saddle) SC(nnzK) SC(nsuper) SC(nlevels) SC(L_size) SC(U_size) SC(u_size) SC(nnzL)
   SC(nnzL_true) SC(flops) SC(flops_dense) SC(nprod) SC(max_r) SC(max_w) SC(max_u) SC(t_order) SC(t_symbolic)
   SC(t_total)
 #undef SC

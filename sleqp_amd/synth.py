@@ -119,3 +119,44 @@ def kkt_full_matrix(N, colptr, rowidx, vals) -> sp.csc_matrix:
     L = sp.csc_matrix((vals, rowidx, colptr), shape=(N, N))
     D = sp.diags(L.diagonal())
     return (L + L.T - D).tocsc()
+
+
+def with_dense_columns(J: sp.csc_matrix, k: int, seed: int = 0, frac: float = 1.0, entries: int | None = None):
+    """J plus k columns (existing variables, chosen at random) that get an entry in a share `frac` of the rows, or in
+    exactly `entries` random rows each (a variable that appears in many constraints).  Returns (J', columns)."""
+    m, n = J.shape
+    rng = np.random.default_rng(seed)
+    cols = np.sort(rng.choice(n, k, replace=False))
+    rr, cc = [], []
+    for c in cols:
+        if entries is not None:
+            rows = np.sort(rng.choice(m, min(entries, m), replace=False))
+        elif frac < 1.0:
+            rows = np.flatnonzero(rng.random(m) < frac)
+        else:
+            rows = np.arange(m)
+        rr.append(rows)
+        cc.append(np.full(rows.size, c))
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    D = sp.csc_matrix((rng.standard_normal(rr.size), (rr, cc)), shape=(m, n))
+    Jd = (J + D).tocsc()
+    Jd.sort_indices()
+    return Jd, cols
+
+
+def with_dense_rows(J: sp.csc_matrix, k: int, seed: int = 0, entries: int | None = None):
+    """J plus k rows (existing constraints, chosen at random) that get an entry in every column, or in `entries`
+    random columns each (a budget-type constraint sum_i x_i <= c).  Returns (J', rows)."""
+    m, n = J.shape
+    rng = np.random.default_rng(seed)
+    rows = np.sort(rng.choice(m, k, replace=False))
+    rr, cc = [], []
+    for r in rows:
+        cols = np.arange(n) if entries is None else np.sort(rng.choice(n, min(entries, n), replace=False))
+        cc.append(cols)
+        rr.append(np.full(cols.size, r))
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    D = sp.csc_matrix((rng.standard_normal(rr.size), (rr, cc)), shape=(m, n))
+    Jd = (J + D).tocsc()
+    Jd.sort_indices()
+    return Jd, rows

@@ -15,11 +15,11 @@ import numpy as np
 
 _NAMES = [
     "Kp", "Ki", "perm", "iperm", "Mp", "Mi", "Mtarget", "prod_ptr", "prod_a", "prod_b", "src", "sn_c0", "sn_r",
-    "sn_rowptr", "sn_rows", "sn_parent", "sn_level", "sn_Loff", "sn_Uoff", "sn_uoff", "child_ptr", "child_idx", "dense_cols",
+    "sn_rowptr", "sn_rows", "sn_parent", "sn_level", "sn_Loff", "sn_Uoff", "sn_uoff", "child_ptr", "child_idx", "dense_cols", "late_cols",
     "rel_ptr", "rel", "level_ptr", "level_sn", "Ar_ptr", "Ar_col", "Ar_src", "Kc_y",
 ]
 _SCALARS = [
-    "N", "n", "m", "saddle", "nnzK", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzL", "nnzL_true", "flops",
+    "N", "n", "m", "my", "n_late", "n_late_rows", "saddle", "nnzK", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzL", "nnzL_true", "flops",
     "flops_dense", "nprod", "max_r", "max_w", "max_u", "t_order", "t_symbolic", "t_total",
 ]
 
@@ -62,7 +62,7 @@ class Plan:
                 rc = lib.hipfact_plan_scalar(p, name.encode(), C.byref(v))
                 assert rc == 0, name
                 setattr(self, name, v.value)
-            for name in ("N", "n", "m", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzK", "nprod"):
+            for name in ("N", "n", "m", "my", "n_late", "n_late_rows", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzK", "nprod"):
                 setattr(self, name, int(getattr(self, name)))
             self.saddle = bool(self.saddle)
         finally:
@@ -91,6 +91,10 @@ class EmulFactor:
         U = np.zeros(max(P.U_size, 1))
         mv = _mvals(P, self.Kx)
         np.add.at(L, P.Mtarget, mv)
+        if P.saddle and P.n_late > 0:
+            # late variables: M = [A_s A_s^T  A_d; A_d^T  -I] - the diagonal of their columns is -1 (k_diag_inactive)
+            late_k = np.nonzero(P.perm >= P.my)[0]
+            L[P.Mtarget[P.Mp[late_k]]] = -1.0
         self.d = np.zeros(P.m)
         for lev in range(P.nlevels):
             for s in P.level_sn[P.level_ptr[lev]:P.level_ptr[lev + 1]]:
@@ -176,19 +180,28 @@ class EmulFactor:
             z = np.empty_like(b)
             z[P.perm] = y
             return z
-        n, m = P.n, P.m
+        n, m, my = P.n, P.m, P.my
         bx, by = b[:n], b[n:]
-        # t_p = A_p bx - by[perm]
-        Av = self.Kx[P.Ar_src] * bx[P.Ar_col]
+        # t_p = A_p bx - by[perm]; rows of constraint rows leave the late columns out (they are unknowns of M), the
+        # row of a late variable x_d is its own unit entry: t = b_d, no b_y term
         seg = np.repeat(np.arange(m), np.diff(P.Ar_ptr))
-        t = np.bincount(seg, weights=Av, minlength=m) - by[P.perm]
+        is_y = P.perm < my
+        late_col = np.zeros(max(n, 1), dtype=bool)
+        late_col[P.late_cols] = True
+        Av = self.Kx[P.Ar_src] * bx[P.Ar_col]
+        Av[late_col[P.Ar_col] & is_y[seg]] = 0.0
+        t = np.bincount(seg, weights=Av, minlength=m).astype(np.float64)
+        t[is_y] -= by[P.perm[is_y]]
         yp = self.solve_m(t) if m > 0 else np.zeros(0)
-        # x_j = b_j - sum_e K[e] y_p[Kc_y[e]]
+        # x_j = b_j - sum_e K[e] y_p[Kc_y[e]] (every column, the late ones too: x_d = b_d - A_d^T y)
         x = bx.copy()
         off = P.Kc_y >= 0
         col_of = np.repeat(np.arange(n), np.diff(P.Kp[:n + 1]))
         x -= np.bincount(col_of[off], weights=self.Kx[off] * yp[P.Kc_y[off]], minlength=n)
-        z = np.empty(n + m)
+        if P.n_late > 0:  # the solve's own value of the late variables is -x_d
+            late_k = np.nonzero(~is_y)[0]
+            assert np.allclose(-yp[late_k], x[P.late_cols[P.perm[late_k] - my]], rtol=1e-8, atol=1e-8 * max(1.0, np.abs(x).max()))
+        z = np.empty(n + my)
         z[:n] = x
-        z[n + P.perm] = yp
+        z[n + P.perm[is_y]] = yp[is_y]
         return z
