@@ -119,6 +119,11 @@ struct SolveItem {
   int a0, a1, sl, nsl;
   long long poff;            // the front's (nsl - 1) x w partial sums in the partial-sum arena
 };
+// Rows of A / columns of K longer than this are not walked by the few lanes of the streaming kernels (16 per row, 8 per
+// column: a dense constraint row or a dense Jacobian column would be thousands of dependent iterations of one lane
+// group) but by a whole workgroup each, in a phase of its own behind the ordinary rows / columns (SaddleMaps::lrows / lcols)
+constexpr int LONG_ROW = 1024;
+constexpr int LONG_COL = 256;
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
 constexpr int WIDE_SLICE_ROWS = 256;
