@@ -120,10 +120,27 @@ struct SolveItem {
   long long poff;            // the front's (nsl - 1) x w partial sums in the partial-sum arena
 };
 // Rows of A / columns of K longer than this are not walked by the few lanes of the streaming kernels (16 per row, 8 per
-// column: a dense constraint row or a dense Jacobian column would be thousands of dependent iterations of one lane
-// group) but by a whole workgroup each, in a phase of its own behind the ordinary rows / columns (SaddleMaps::lrows / lcols)
+// column: a dense constraint row or a dense Jacobian column would be tens of thousands of dependent iterations of one
+// lane group).  They are cut into segments of LONG_SEG entries; a workgroup takes one segment, leaves its partial sum
+// in a scratch slot, and the workgroup that arrives last (a counter per row / column) adds the partials IN SEGMENT
+// ORDER and finishes the row - deterministic, and a 10^5-entry row is spread over fifty workgroups.
 constexpr int LONG_ROW = 1024;
 constexpr int LONG_COL = 256;
+constexpr int LONG_SEG = 2048;
+struct LongSeg {
+  int id;         // pivot position of the row / index of the column of K
+  int begin, end; // entries [begin, end) of Ar_* / of K
+  int idx, nseg;  // this is segment idx of nseg
+  int uid;        // counter of the row / column (unique over rows and columns of a plan)
+  int poff;       // first partial-sum slot of the row / column
+  int pad;
+};
+// the same for product lists of more than MV_LONG pairs (the diagonal entry of a dense row of A in S = A A^T)
+struct LongProd {
+  long long e;           // entry of M
+  long long begin, end;  // pairs [begin, end)
+  int idx, nseg, uid, poff;
+};
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
 constexpr int WIDE_SLICE_ROWS = 256;

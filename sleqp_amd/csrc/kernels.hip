@@ -41,6 +41,39 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
 }
+// sum over the workgroup in a fixed order (shuffle tree inside the waves, then the waves' partials in wave order);
+// the result is valid in thread 0.  lds: NT / 64 doubles.
+template <int NT>
+__device__ __forceinline__ double block_sum_fixed(double s, double* lds) {
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double a = 0.0;
+  if (threadIdx.x == 0)
+    for (int q = 0; q < NT / 64; ++q) a += lds[q];
+  return a;
+}
+// Thread 0 of a workgroup hands in the partial sum of its segment.  Returns true (in thread 0) for the workgroup that
+// arrives last, with the sum of all partials in segment order; the counter is put back to zero for the next use.
+__device__ __forceinline__ bool seg_arrive(double partial, int poff, int idx, int nseg, double* __restrict__ segpart,
+                                           unsigned int* __restrict__ cnt, double& total) {
+  if (nseg == 1) {
+    total = partial;
+    return true;
+  }
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(segpart + poff + idx),
+                     (unsigned long long)__double_as_longlong(partial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned int seen = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (seen + 1u != (unsigned int)nseg) return false;
+  double a = 0.0;
+  for (int q = 0; q < nseg; ++q)
+    a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(segpart + poff + q),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  total = a;
+  return true;
+}
 #include "kernels_mvals.inc"
 #include "kernels_front_pivot.inc"
 #include "kernels_front_update.inc"

@@ -1799,6 +1799,7 @@ def test_krylov_loops_with_dense_jacobian_columns(fact, method, mode):
     HL = sp.tril(B @ B.T + 0.5 * sp.eye(n), format="csc")
     HL.sort_indices()
     H = SpMat(fact, SleqpMat.from_scipy(HL))
+    Hs = (HL + HL.T - sp.diags(HL.diagonal())).tocsr()
     g = rng.standard_normal(n)
     N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
     for radius, tol in ((1e3, 1e-4), (30.0, 1e-6)):
@@ -1810,7 +1811,14 @@ def test_krylov_loops_with_dense_jacobian_columns(fact, method, mode):
             step, dual, its = fact.tr_solve(H, g, radius, method=method, stat_tol=tol, max_iter=200)
             if method == 0:
                 assert abs(its - its_ref) <= 1, (its, its_ref)
-            assert rel_err(step, want) <= (1e-6 if radius > 100 else 1e-7), (radius, device_loop)
+            if method == 1 and radius < 100:
+                # on the boundary GLTR minimises the model over the whole Krylov space while Steihaug's CG stops where
+                # its path leaves the region: another point of the boundary, with a model value at least as good
+                q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
+                assert abs(np.linalg.norm(step) - radius) <= 1e-8 * radius and q(step) <= q(want) + 1e-9 * abs(q(want))
+            else:
+                # (interior case: GLTR and CG stop at stat_tol by tests of their own - the iterates agree to that order)
+                assert rel_err(step, want) <= ((5e-5 if method == 1 else 1e-6) if radius > 100 else 1e-7), (radius, device_loop)
             assert np.abs(J @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(J).sum(axis=1).max()
             assert np.linalg.norm(step) <= radius * (1 + 1e-10)
     H.free()
