@@ -141,6 +141,38 @@ struct LongProd {
   long long begin, end;  // pairs [begin, end)
   int idx, nseg, uid, poff;
 };
+// ---- the top of the solve tree as ONE dense block (runtime_plan.inc: top block) ----------------------------------
+// The last levels of the tree hold a handful of fronts each and cost the solve ~2.7 us per level and direction in
+// pure hop latency.  For the fronts T of those levels (closed under "parent", nT columns in all) the forward sweep is
+// x^_T = X_T f_T with X_T = inv(L_TT), the backward sweep y_T = X_T^T D_T^-1 x^_T: two dense products, each split
+// over many workgroups by rows, two hops instead of two per level.  X_T is formed once per factorisation (lazily:
+// the second solve pays for it) from the solve panels of the fronts of T.
+struct TopBlockItem {
+  long long off;  // this item's thread-major rows in the arena (forward: rows of X_T; backward: rows of X_T^T D^-1)
+  int r0, nr;     // rows [r0, r0 + nr) of the block (T-local numbering = pivot order)
+  int Q, E;       // column classes, entries per thread (thread (rho, q) owns columns q + Q e, e < E)
+};
+struct TopFront {
+  int item;    // its SolveItem (single-slice fronts only)
+  int parent;  // index of the parent's TopFront, -1: root
+  int tl0;     // T-local index of its first column
+  int pad;
+};
+struct TopChunk {
+  int front;  // TopFront
+  int j0;     // first of (at most TOP_CB) columns of that front
+};
+constexpr int TOP_CB = 8;
+struct TopBlockIn {
+  int nT, ntf, ntb;
+  const TopBlockItem* __restrict__ items;  // ntf forward items, then ntb backward items
+  const double* __restrict__ XTf;
+  const double* __restrict__ XTb;
+  const int* __restrict__ tpos;       // T-local index -> pivot position
+  const int* __restrict__ gptr;       // nT + 1: sources of f_T[i] among the update vectors of the fronts below T ...
+  const long long* __restrict__ gsrc; // ... as offsets into uvec (added in this fixed order)
+  double* __restrict__ xhatT2;        // 2 x nT exchange slots (by launch parity), sentinel between uses
+};
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
 constexpr int WIDE_SLICE_ROWS = 256;
