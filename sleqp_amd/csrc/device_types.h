@@ -172,6 +172,8 @@ struct TopBlockIn {
   const int* __restrict__ gptr;       // nT + 1: sources of f_T[i] among the update vectors of the fronts below T ...
   const long long* __restrict__ gsrc; // ... as offsets into uvec (added in this fixed order)
   double* __restrict__ xhatT2;        // 2 x nT exchange slots (by launch parity), sentinel between uses
+  double* __restrict__ tT2;           // the same for the rows of the right-hand side t that belong to T ...
+  int ntr;                            // ... formed by the FIRST ntr workgroups of the launch (64 rows each; 0: t is in y)
 };
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
