@@ -163,6 +163,8 @@ struct TopChunk {
   int j0;     // first of (at most TOP_CB) columns of that front
 };
 constexpr int TOP_CB = 8;
+// LDS doubles of a k_solve_tree workgroup; a top-block item needs nT + 1024 + (nT + 1 + sources + 1) / 2 of them
+constexpr int TOP_LDS = 7 * 1024 + 512;
 struct TopBlockIn {
   int nT, ntf, ntb;
   const TopBlockItem* __restrict__ items;  // ntf forward items, then ntb backward items
