@@ -37,10 +37,10 @@ def build():
         # top forward
         ("  // the slots the PREVIOUS launch exchanged through go back to the sentinel (this launch uses the other copy)", "  TRS(1);\n"),
         ("  constexpr int GK = 6;", "  TRS(4);\n"),
-        ("    post_f64(B.xhatT2 + (size_t)par * nT + I.r0 + tid, s2);\n  }\n}", None, "TAIL"),
+        ("      post_f64(B.xhatT2 + (size_t)par * nT + I.r0 + tid, s2);\n    }\n  }\n}", None, "TAIL"),
         # top backward
         ("  const double* __restrict__ xh = B.xhatT2 + (size_t)par * nT;", "  TRS(1);\n"),
-        ("    y[k] = s2;\n    post_f64(ysol + k, s2);\n  }\n}", None, "TAIL"),
+        ("      y[k] = s2;\n      post_f64(ysol + k, s2);\n    }\n  }\n}", None, "TAIL"),
     ]
     for r in rep:
         assert s.count(r[0]) == 1, (r[0], s.count(r[0]))

@@ -1676,7 +1676,10 @@ def test_full_size_krylov_loops(fact):
     step, _, its1 = fact.steihaug(Hd, g, 1e6, stat_tol=1e-3, max_iter=300)
     assert fact.info("cg_device_runs") == runs + 1 and fact.info("cg_device_fallbacks") == 0
     assert 0 < its0 < 300 and its1 == its0
-    assert rel_err(step, want) <= 1e-9
+    # (the first projection of the host-driven run is the first solve of the factorisation: the ordinary tree launch;
+    # every other one goes through the top block, which sums in another order - rounding-level differences that the
+    # CG recurrence carries along)
+    assert rel_err(step, want) <= 1e-8
     assert np.abs(A @ step).max() <= 1e-9 * anorm * max(1.0, np.abs(step).max())
     q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
     assert q(step) < 0.0
