@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
-PROFILE_TAG = "r3"
+PROFILE_TAG = "r4"
 
 
 def make_problem(workload: str, seed: int):
@@ -451,6 +451,146 @@ def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     shim.sleqp_fact_release(C.byref(fact))
     shim.sleqp_settings_release(C.byref(settings))
     return out
+
+
+def device_unit(J, local_rank, reps=12, solves=20):
+    """Device-resident numeric refactorisation + solve of K(J) (values and right-hand side in HBM), plan statistics."""
+    import torch
+
+    from sleqp_amd import synth
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    f = HipFact(device=local_rank)
+    t0 = time.perf_counter()
+    f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    cold = time.perf_counter() - t0
+    dev = f"cuda:{local_rank}"
+    d_vals = torch.from_numpy(vx).to(dev)
+    b = torch.randn(N, dtype=torch.float64, device=dev)
+    z = torch.empty_like(b)
+    for _ in range(3):
+        f.refactor_device(d_vals.data_ptr())
+        f.solve_device(b.data_ptr(), z.data_ptr())
+    f.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f.refactor_device(d_vals.data_ptr())
+        f.solve_device(b.data_ptr(), z.data_ptr())
+    f.synchronize()
+    t_unit = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f.refactor_device(d_vals.data_ptr())
+    f.synchronize()
+    t_fac = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(solves):
+        f.solve_device(b.data_ptr(), z.data_ptr())
+    f.synchronize()
+    t_sol = (time.perf_counter() - t0) / solves
+    f.check()
+    import scipy.sparse as sp
+
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    zz, bb = z.cpu().numpy(), b.cpu().numpy()
+    resid = float(np.abs(K @ zz - bb).max() / (abs(K).sum(axis=1).max() * np.abs(zz).max() + np.abs(bb).max()))
+    out = {"factor_plus_solve_ms": t_unit * 1e3, "factor_ms": t_fac * 1e3, "solve_ms": t_sol * 1e3, "levels": int(f.info("nlevels")),
+           "fronts": int(f.info("nsuper")), "nnzL": f.info("nnzL_true"), "flops": f.info("flops"), "late_columns": int(f.info("late_columns")),
+           "late_rows": int(f.info("late_rows")), "analysis_s": f.info("analysis_s"), "cold_set_matrix_s": cold, "scaled_residual": resid}
+    f.free()
+    return out
+
+
+def structural_robustness_bench(J4, local_rank):
+    """SURVEY a8 / VERDICT round 3 item 2: the inputs an ordering of K itself (MA57 / UMFPACK: fact_ma57.c:314-345,
+    761-763) takes in its stride, device-resident next to the base: BASELINE configs[3] plus one dense constraint row,
+    plus 16 / 100 dense Jacobian columns; n = 2e4 / m = 1e4 with 100 dense columns and with 200 columns of 300 entries."""
+    from sleqp_amd import synth
+
+    out = {}
+    try:
+        base = device_unit(J4, local_rank)
+        out["config4_base"] = base
+        for name, Jx in (("config4_plus_1_dense_row", synth.with_dense_rows(J4, 1, 1)[0]),
+                         ("config4_plus_16_dense_columns", synth.with_dense_columns(J4, 16, 3)[0]),
+                         ("config4_plus_100_dense_columns", synth.with_dense_columns(J4, 100, 3)[0])):
+            r = device_unit(Jx, local_rank)
+            r["factor_plus_solve_vs_base"] = r["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
+            out[name] = r
+        J2 = synth.banded_jacobian(20000, 10000, 20, 200, 0)
+        b2 = device_unit(J2, local_rank)
+        out["n2e4_base"] = b2
+        for name, Jx, mmd in (("n2e4_plus_100_dense_columns", synth.with_dense_columns(J2, 100, 1)[0], 2.36e6),
+                              ("n2e4_plus_200_columns_of_300", synth.with_dense_columns(J2, 200, 1, entries=300)[0], 3.60e6)):
+            r = device_unit(Jx, local_rank)
+            r["factor_plus_solve_vs_base"] = r["factor_plus_solve_ms"] / b2["factor_plus_solve_ms"]
+            r["nnzL_vs_superlu_mmd_on_K"] = r["nnzL"] / mmd
+            out[name] = r
+        out["note"] = ("numeric refactorisation + solve with values and right-hand side in HBM; dense columns are eliminated late inside the "
+                       "tree (M = [A_s A_s^T  A_d; A_d^T  -I]), dense rows ordered last; SuperLU-MMD nnz(L) on K measured with "
+                       "scripts/ordering_probe.py superlu (2.36e6 / 3.60e6)")
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)[:300]
+    return out
+
+
+def dense_chain_bench(local_rank):
+    """BASELINE configs[2] (uniform n = 1e4, m = 5e3: A A^T fills in completely, the tree is a chain of dense fronts):
+    the MFMA-bound configuration, a few seconds, so that the driver's line carries the matrix-core evidence too."""
+    import torch
+
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    try:
+        J, N, cp, ri, vx, b = make_problem("uniform_n1e4_m5e3", 0)
+        f = HipFact(device=local_rank)
+        f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+        dev = f"cuda:{local_rank}"
+        d_vals = torch.from_numpy(vx).to(dev)
+        db = torch.from_numpy(b).to(dev)
+        z = torch.empty_like(db)
+        for _ in range(3):
+            f.refactor_device(d_vals.data_ptr())
+            f.solve_device(db.data_ptr(), z.data_ptr())
+        f.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f.refactor_device(d_vals.data_ptr())
+            f.solve_device(db.data_ptr(), z.data_ptr())
+        f.synchronize()
+        t_unit = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f.refactor_device(d_vals.data_ptr())
+        f.synchronize()
+        t_fac = (time.perf_counter() - t0) / reps
+        f.set_option("profile", -1)
+        f.set_option("profile", 1)
+        for _ in range(3):
+            f.refactor_device(d_vals.data_ptr())
+        f.synchronize()
+        best = (f.info("prof_schur_best_flops"), f.info("prof_schur_best_ms"))
+        f.set_option("profile", 0)
+        flops = f.info("flops_dense")
+        out = {"workload": "uniform_n1e4_m5e3", "rate": 1.0 / t_unit, "unit": "factor+solve/s", "factor_only_ms": t_fac * 1e3,
+               "flops_dense": flops, "levels": int(f.info("nlevels")),
+               "roofline": {"bound": "mfma", "achieved": flops / t_fac / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flops / t_fac / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                            "largest_launch": {"TFLOPs": best[0] / max(best[1], 1e-9) / 1e9, "frac": best[0] / max(best[1], 1e-9) / 1e9 / MFMA_F64_PEAK_TFLOPS,
+                                               "note": "the Schur-update launch with the most flops (HIP events on the handle's stream)"}}}
+        try:
+            txt = open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_mfma_config3.txt")).read()
+            out["pmc"] = {"file": f"profiles/{PROFILE_TAG}_pmc_mfma_config3.txt", "summary": txt.strip().splitlines()[-6:]}
+        except OSError:
+            out["pmc"] = None
+        f.free()
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def working_set_change_bench(J, local_rank, steps=12):
@@ -866,9 +1006,9 @@ def main():
                 fl_b, us_b = schur_best[0], schur_best[1] * 1e3
                 out["roofline"]["largest_launch"] = {"flops": fl_b, "us": us_b, "achieved": fl_b / us_b / 1e6, "unit": "TFLOP/s",
                                                      "frac": fl_b / us_b / 1e6 / MFMA_F64_PEAK_TFLOPS,
-                                                     "note": "structural flops u (u + 1) w of one level's Schur launch over its HIP-event "
-                                                             "duration (config 3: executed flops and matrix-pipe busy share in "
-                                                             "profiles/r3_pmc_mfma_config3.txt)"}
+                                                     "note": ("structural flops u (u + 1) w of one level's Schur launch over its HIP-event "
+                                                              "duration (config 3: executed flops and matrix-pipe busy share in "
+                                                              "profiles/%s_pmc_mfma_config3.txt)" % PROFILE_TAG)}
         if dom == "factorT" and fact.info("spanel_folded"):
             # the launch also builds the solve panels of EVERY front (filler workgroups between its levels): reads each
             # factor panel once more, writes both thread-major copies.  Not part of SURVEY 8(d)'s factor bytes, hence
@@ -895,6 +1035,9 @@ def main():
                 if "new_pattern_s" in fv and "solve_plus_solution_ms" in out["boundary"]:
                     out["new_pattern_unit_s"] = fv["new_pattern_s"] + out["boundary"]["solve_plus_solution_ms"] * 1e-3
                     out["cold_pattern_unit_s"] = fv["cold_first_call_s"] + out["boundary"]["solve_plus_solution_ms"] * 1e-3
+            if args.workload == "banded_n1e5_m5e4":
+                out["structural_robustness"] = structural_robustness_bench(J, local_rank)
+                out["dense_chain"] = dense_chain_bench(local_rank)
         if world == 1 and not args.no_ceilings:
             out["measured_ceilings"] = measured_ceilings(f"cuda:{local_rank}")
         if world == 1 and not args.no_cpu_baseline:
