@@ -819,6 +819,25 @@ def main():
     t_solve = (time.perf_counter() - t0) / nsolve
     fact.check()
     passes = 1.0 + fact.info("last_iters")
+    top_block = {"columns": int(fact.info("top_block_cols")), "levels": int(fact.info("top_block_levels")),
+                 "items_per_direction": int(fact.info("top_block_items")), "active": bool(fact.info("top_block_active")),
+                 "note": "the last levels of the solve tree as two dense products from the second solve of a factorisation on"}
+    # the same without the top block (ordinary tree launch for every level)
+    fact.set_option("top_block_after", 0)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    for _ in range(3):
+        fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+    fact.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsolve):
+        fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+    fact.synchronize()
+    top_block["ms_per_solve_without"] = (time.perf_counter() - t0) / nsolve * 1e3
+    fact.set_option("top_block_after", 2)
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    for _ in range(3):
+        fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+    fact.synchronize()
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -964,7 +983,7 @@ def main():
                          "algorithmic_bytes_basis": "structural nnz(L) (column counts); stored dense panels: x%.3f" % (1.0 / true_frac),
                          "avg_launch_us": prof[dom]["avg_launch_us"]},
             "kernels": prof,
-            "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3,
+            "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3, "top_block": top_block,
                            "passes_per_solve": passes, "algorithmic_GBps": sbytes * passes / t_solve / 1e9,
                            "frac_of_hbm_peak": sbytes * passes / t_solve / 1e9 / HBM_PEAK_GBS,
                            "last_omega": fact.info("last_omega"), "kappa_est": fact.info("kappa_est")},
