@@ -1,4 +1,4 @@
-// Probe: clocks of the 16 x 16 diagonal-block chain (dev_diag_block of kernels.hip) on one wave, and its
+// Probe: clocks of the 16 x 16 diagonal-block chain (dev_diag_block of kernels_front_pivot.inc) on one wave, and its
 // result against a plain host LDL^T + inverse.  Build twice to compare the instruction orders:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 diag_chain.hip -o diag_chain
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHIPFACT_DIAG_INTERLEAVED diag_chain.hip -o diag_chain_interleaved
@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "../../sleqp_amd/csrc/device_types.h"
-#include "../../sleqp_amd/csrc/kernels.hip"
+#include "../../sleqp_amd/csrc/kernels_factor.hip"
 using namespace hipfact;
 
 __global__ __launch_bounds__(64) void k_probe(const double* __restrict__ Ain, double* __restrict__ out,

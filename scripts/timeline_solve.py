@@ -20,7 +20,7 @@ NB = 4096
 
 
 def inline_parts(path):
-    """The kernels live in kernels_*.inc files included by kernels.hip: expand them in the scratch copy, so that the
+    """The kernels live in kernels_*.inc files included by kernels_solve.hip: expand them in the scratch copy, so that the
     patches below see one text."""
     import re
 
@@ -33,7 +33,7 @@ def inline_parts(path):
 def build():
     shutil.rmtree(SCRATCH, ignore_errors=True)
     shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
-    p = os.path.join(SCRATCH, "kernels.hip")
+    p = os.path.join(SCRATCH, "kernels_solve.hip")
     inline_parts(p)
     s = open(p).read()
     s = s.replace("typedef double d4_t __attribute__((ext_vector_type(4)));",
@@ -61,7 +61,7 @@ def build():
         s = s[:a] + "    g_st[(g_kid * %d + blockIdx.x) * 8 + 4] = wall_clock64();\n" % NB + s[a:]
     assert s.count("TRS(") >= 6
     open(p, "w").write(s)
-    h = os.path.join(SCRATCH, "hipfact.hip")
+    h = os.path.join(SCRATCH, "kernels_solve.hip")
     t = open(h).read()
     t += ('\nextern "C" int hipfact_debug_trace_solve(long long* out) {\n'
           f"  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_st), sizeof(long long) * 2 * {NB} * 8);\n}}\n")

@@ -17,7 +17,7 @@ def build():
 
     shutil.rmtree(SCRATCH, ignore_errors=True)
     shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
-    p = os.path.join(SCRATCH, "kernels.hip")
+    p = os.path.join(SCRATCH, "kernels_solve.hip")
     text = open(p).read()
     text = re.sub(r'^#include "(kernels_\w+\.inc)"$', lambda m: open(os.path.join(SCRATCH, m.group(1))).read(), text, flags=re.M)
     s = text
@@ -58,7 +58,7 @@ def build():
     seg = seg.replace("  __syncthreads();\n  double acc = 0.0;", "  __syncthreads();\n  TRS(2);\n  double acc = 0.0;")
     s = s[:a] + seg + s[b:]
     open(p, "w").write(s)
-    h = os.path.join(SCRATCH, "hipfact.hip")
+    h = os.path.join(SCRATCH, "kernels_solve.hip")
     t = open(h).read()
     t += ('\nextern "C" int hipfact_debug_trace_tree(long long* out) {\n'
           f"  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_st), sizeof(long long) * {NB} * 8);\n}}\n")

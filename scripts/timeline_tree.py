@@ -17,7 +17,7 @@ NB = 4096
 
 
 def inline_parts(path):
-    """The kernels live in kernels_*.inc files included by kernels.hip: expand them in the scratch copy, so that the
+    """The kernels live in kernels_*.inc files included by kernels_solve.hip: expand them in the scratch copy, so that the
     patches below see one text."""
     import re
 
@@ -30,7 +30,7 @@ def inline_parts(path):
 def build():
     shutil.rmtree(SCRATCH, ignore_errors=True)
     shutil.copytree(SRC, SCRATCH, ignore=shutil.ignore_patterns("*.so", "*.o"))
-    p = os.path.join(SCRATCH, "kernels.hip")
+    p = os.path.join(SCRATCH, "kernels_solve.hip")
     inline_parts(p)
     s = open(p).read()
     s = s.replace("typedef double d4_t __attribute__((ext_vector_type(4)));",
@@ -52,7 +52,7 @@ def build():
     assert seg.count("TRS(") == 7, seg.count("TRS(")
     s = s[:a] + seg + s[b:]
     open(p, "w").write(s)
-    h = os.path.join(SCRATCH, "hipfact.hip")
+    h = os.path.join(SCRATCH, "kernels_solve.hip")
     t = open(h).read()
     t += ('\nextern "C" int hipfact_debug_trace_tree(long long* out) {\n'
           f"  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_st), sizeof(long long) * {NB} * 8);\n}}\n")

@@ -5,7 +5,8 @@
 // state.  All numerics run on the device; there is no CPU fallback: without a
 // usable GPU hipfact_create fails with HIPFACT_EDEVICE.
 //
-// One translation unit (the kernels are compiled together with their launchers), split by role:
+// The host translation unit (the kernels are compiled separately: kernels_factor.hip / kernels_solve.hip, declared in the
+// generated kernels_decl.h), split by role:
 //   runtime_types.inc   buffers, plan state, the handle          abi_core.inc         create .. solution (SleqpFact)
 //   runtime_plan.inc    upload of a plan, work items             abi_working_set.inc  superset plans, assemble_kkt
 //   runtime_queue.inc   factor / solve queues, graphs, cache     abi_krylov.inc       products, Steihaug CG, GLTR
@@ -34,14 +35,9 @@
 #include "plan.h"
 #include "tridiag_tr.h"
 
-// single translation unit: the kernels are compiled together with their launcher
-#include "kernels.hip"
-#define DENSE_COLS_KERNELS
-#include "dense_cols.inc"
-#undef DENSE_COLS_KERNELS
-#define KRYLOV_DEVICE_KERNELS
-#include "krylov_device.inc"
-#undef KRYLOV_DEVICE_KERNELS
+// the kernels are translation units of their own (kernels_factor.hip, kernels_solve.hip); this one sees their declarations
+#include "kernel_types.h"
+#include "kernels_decl.h"
 
 #include "runtime_types.inc"
 #include "runtime_plan.inc"
@@ -53,16 +49,3 @@ extern "C" {
 #include "abi_krylov.inc"
 #include "abi_options.inc"
 }  // extern "C"
-
-#ifdef HIPFACT_TRACE
-// in-kernel timeline of the dataflow launch (scripts/timeline.py; never part of the product build)
-extern "C" int hipfact_debug_trace(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_trace), sizeof(long long) * hipfact::TRACE_WGS * 8);
-}
-extern "C" int hipfact_debug_trace_owner(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_own), sizeof(long long) * hipfact::TRACE_WGS * 8);
-}
-extern "C" int hipfact_debug_trace_pivot(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipfact::g_piv), sizeof(long long) * hipfact::TRACE_WGS * 24);
-}
-#endif

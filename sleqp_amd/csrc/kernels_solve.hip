@@ -1,4 +1,5 @@
-// gfx950 (MI355X / CDNA4) kernels of the hipfact KKT backend.
+// gfx950 (MI355X / CDNA4) kernels of the hipfact KKT backend: translation unit of the SOLVES, the saddle-point front / back end,
+// the vector and product kernels, the dense-column correction and the device-controlled CG.
 //
 // Numeric phase of the supernodal multifrontal LDL^T (replacing what the
 // reference delegates to MA57 / CHOLMOD / UMFPACK / LAPACK behind
@@ -31,56 +32,38 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "kernel_types.h"
 
 namespace hipfact {
-
-constexpr int FB = 256;  // threads per block
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-// sum over the workgroup in a fixed order (shuffle tree inside the waves, then the waves' partials in wave order);
-// the result is valid in thread 0.  lds: NT / 64 doubles.
-template <int NT>
-__device__ __forceinline__ double block_sum_fixed(double s, double* lds) {
-  s = wave_sum(s);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
-  __syncthreads();
-  double a = 0.0;
-  if (threadIdx.x == 0)
-    for (int q = 0; q < NT / 64; ++q) a += lds[q];
-  return a;
-}
-// Thread 0 of a workgroup hands in the partial sum of its segment.  Returns true (in thread 0) for the workgroup that
-// arrives last, with the sum of all partials in segment order; the counter is put back to zero for the next use.
-__device__ __forceinline__ bool seg_arrive(double partial, int poff, int idx, int nseg, double* __restrict__ segpart,
-                                           unsigned int* __restrict__ cnt, double& total) {
-  if (nseg == 1) {
-    total = partial;
-    return true;
-  }
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(segpart + poff + idx),
-                     (unsigned long long)__double_as_longlong(partial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned int seen = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (seen + 1u != (unsigned int)nseg) return false;
-  double a = 0.0;
-  for (int q = 0; q < nseg; ++q)
-    a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(segpart + poff + q),
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  total = a;
-  return true;
-}
-#include "kernels_mvals.inc"
-#include "kernels_front_pivot.inc"
-#include "kernels_front_update.inc"
+#include "kernels_common.inc"
 #include "kernels_solve_level.inc"
-#include "kernels_factor_top.inc"
 #include "kernels_solve_wide.inc"
 #include "kernels_solve_tree.inc"
 #include "kernels_saddle.inc"
 #include "kernels_vector.inc"
+}  // namespace hipfact
+
+// kernels that live next to the host code that launches them (their host halves are compiled with hipfact.hip)
+#define DENSE_COLS_KERNELS
+#include "dense_cols.inc"
+#undef DENSE_COLS_KERNELS
+#define KRYLOV_DEVICE_KERNELS
+#include "krylov_device.inc"
+#undef KRYLOV_DEVICE_KERNELS
+
+// ---- the instances of the kernel templates the host runtime launches (it sees declarations only: kernels_decl.h)
+namespace hipfact {
+#define INST_CG(L)                                                                                                   \
+  template __global__ void k_cg_spmv_dots<L>(int, const CgCtl*, const int*, const int*, const double*, const int*,   \
+                                             const int*, const double*, const double*, const double*, const double*, \
+                                             double*, double*);
+INST_CG(1)
+INST_CG(4)
+INST_CG(16)
+INST_CG(64)
+#undef INST_CG
+template __global__ void k_x_saddle<true>(int, int, const int*, const double*, const int*, const int*, SaddleMaps,
+                                          const double*, const double*, double*, const int*, int*);
+template __global__ void k_x_saddle<false>(int, int, const int*, const double*, const int*, const int*, SaddleMaps,
+                                           const double*, const double*, double*, const int*, int*);
 }  // namespace hipfact

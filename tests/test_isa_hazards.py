@@ -78,7 +78,7 @@ def test_hazard_checker_itself():
 def test_dpp_sources_are_two_wait_states_away_from_their_producers(tmp_path):
     out = tmp_path / "hipfact.s"
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-                           "--cuda-device-only", "-S", os.path.join(CSRC, "hipfact.hip"), "-o", str(out)],
+                           "--cuda-device-only", "-S", os.path.join(CSRC, "kernels_factor.hip"), "-o", str(out)],
                           cwd=CSRC, stderr=subprocess.DEVNULL)
     checked = check_stream(open(out))
     assert checked > 300  # the diagonal block alone has ~170 of them per instantiation
