@@ -40,6 +40,30 @@ void parallel_chunks(int n, F fn, int grain = 2048) {
   for (auto& th : pool) th.join();
 }
 
+// the same with the chunks handed out on demand (grain iterations at a time): for loops whose cost per iteration is
+// very uneven - a dense constraint row is 10^5 times the work of an ordinary one, and the late rows sit together at
+// the end of the pivot order, i.e. in ONE chunk of a static partition
+template <class F>
+void parallel_dynamic(int n, F fn, int grain = 256) {
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int nt = std::max(1, std::min({hw, 32, n / (4 * grain) + 1}));
+  if (nt == 1) {
+    fn(0, n, 0);
+    return;
+  }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([&, t] {
+      for (;;) {
+        const int b = next.fetch_add(grain);
+        if (b >= n) break;
+        fn(b, std::min(n, b + grain), t);
+      }
+    });
+  for (auto& th : pool) th.join();
+}
+
 double now_s() {
   using clk = std::chrono::steady_clock;
   return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
@@ -706,8 +730,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     // rows are independent (count, prefix, fill; one marker array per thread).  Row a < my: the rows that share an
     // ordinary column with it and the late variables among its columns; vertex my + t: the rows of late column t.
     std::vector<int64_t> deg(m + 1, 0);
-    parallel_chunks(my, [&](int lo, int hi, int) {
-      std::vector<int> mark(my, -1);
+    std::vector<std::vector<int>> mark_of((size_t)32);  // (one marker array per thread, kept across its chunks)
+    parallel_dynamic(my, [&](int lo, int hi, int tid) {
+      std::vector<int>& mark = mark_of[(size_t)tid];
+      if (mark.empty()) mark.assign((size_t)my, -1);
       for (int a = lo; a < hi; ++a) {
         mark[a] = a;
         int64_t c = 0;
@@ -732,8 +758,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     for (int a = 0; a < m; ++a) deg[a + 1] += deg[a];
     g.ptr.assign(deg.begin(), deg.end());
     huge_resize(g.adj, (size_t)g.ptr[m]);
-    parallel_chunks(my, [&](int lo, int hi, int) {
-      std::vector<int> mark(my, -1);
+    for (auto& mk : mark_of) std::fill(mk.begin(), mk.end(), -1);
+    parallel_dynamic(my, [&](int lo, int hi, int tid) {
+      std::vector<int>& mark = mark_of[(size_t)tid];
+      if (mark.empty()) mark.assign((size_t)my, -1);
       for (int a = lo; a < hi; ++a) {
         mark[a] = a;
         int64_t o = g.ptr[a];
@@ -1098,8 +1126,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   huge_resize(P.Mtarget, (size_t)P.Mp[m]);
   {
     std::atomic<bool> bad{false};
-    parallel_chunks(ns, [&](int lo, int hi, int) {
-      std::vector<int> pos(m, -1);
+    std::vector<std::vector<int>> pos_sn((size_t)32);
+    parallel_dynamic(ns, [&](int lo, int hi, int tid) {
+      std::vector<int>& pos = pos_sn[(size_t)tid];
+      if (pos.empty()) pos.assign((size_t)m, -1);
       for (int s = lo; s < hi; ++s) {
         const std::vector<int>& rs = sn[s].rows;
         const int r = (int)rs.size();
@@ -1146,6 +1176,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     BigVec<int64_t> fill;
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 1) {
+        tick("  products counted");
         for (int64_t e = 0; e < P.Mp[m]; ++e) P.prod_ptr[e + 1] += P.prod_ptr[e];
         P.nprod = P.prod_ptr[P.Mp[m]];
         if (P.nprod > (int64_t)1 << 31) {
@@ -1162,8 +1193,10 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         else
           std::copy(P.prod_ptr.begin(), P.prod_ptr.end() - 1, fill.begin());
       }
-      parallel_chunks(m, [&](int lo, int hi, int) {
-        std::vector<int> pos(m, -1);
+      std::vector<std::vector<int>> pos_of((size_t)32);
+      parallel_dynamic(m, [&](int lo, int hi, int tid) {
+        std::vector<int>& pos = pos_of[(size_t)tid];
+        if (pos.empty()) pos.assign((size_t)m, -1);
         for (int k = lo; k < hi; ++k) {
           for (int64_t e = P.Mp[k]; e < P.Mp[k + 1]; ++e) pos[P.Mi[e]] = (int)(e - P.Mp[k]);
           const int b = perm[k];
@@ -1213,6 +1246,7 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
         }
       });
     }
+    tick("  products filled");
     // SpMV structures
     // (the row of a late variable x_d in this CSR: its own unit entry, so that the right-hand side of its
     // equation -x_d' + A_d^T y = b_d is b_d)
