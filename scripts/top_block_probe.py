@@ -11,9 +11,9 @@ J, N, cp, ri, vx, b = make_problem(wl, 0)
 d_vals = torch.from_numpy(vx).cuda()
 db = torch.from_numpy(b).cuda()
 ref = None
-for after, cap in ((0, 2048), (2, 1536), (2, 2048), (2, 2560), (2, 3200), (2, 4096)):
+for after, cap, single in ((0, 2048, 0), (2, 2048, 0), (2, 2048, 1), (2, 2560, 1)):
     f = HipFact(device=0)
-    f.set_option("top_block_after", after); f.set_option("top_block_max", cap)
+    f.set_option("top_block_after", after); f.set_option("top_block_max", cap); f.set_option("top_block_single", single)
     f.set_matrix(SleqpMat(N, N, cp, ri, vx))
     z = torch.empty_like(db)
     for _ in range(4):
@@ -35,6 +35,6 @@ for after, cap in ((0, 2048), (2, 1536), (2, 2048), (2, 2560), (2, 3200), (2, 40
             f.solve_device(db.data_ptr(), z.data_ptr())
     f.synchronize()
     t_sqp = (time.perf_counter() - t0) / 5
-    print(f"after {after} cap {cap}: top block cols {int(f.info('top_block_cols'))} levels {int(f.info('top_block_levels'))} items {int(f.info('top_block_items'))} "
+    print(f"after {after} cap {cap} single {single}: top block cols {int(f.info('top_block_cols'))} levels {int(f.info('top_block_levels'))} items {int(f.info('top_block_items'))} "
           f"builds {int(f.info('top_block_builds'))} active {int(f.info('top_block_active'))} | solve {t_sol*1e3:.4f} ms  sqp(1:100) {t_sqp*1e3:.3f} ms  diff vs plain {err:.2e}", flush=True)
     f.free()

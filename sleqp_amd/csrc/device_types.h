@@ -176,6 +176,7 @@ struct TopBlockIn {
   double* __restrict__ xhatT2;        // 2 x nT exchange slots (by launch parity), sentinel between uses
   double* __restrict__ tT2;           // the same for the rows of the right-hand side t that belong to T ...
   int ntr;                            // ... formed by the FIRST ntr workgroups of the launch (64 rows each; 0: t is in y)
+  int single;                         // 1: ONE product y_T = Z f_T with Z = X_T^T D_T^-1 X_T (= inv(S_T)); XTf holds the rows of Z, ntb = 0
 };
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
