@@ -11,7 +11,7 @@ J, N, cp, ri, vx, b = make_problem(wl, 0)
 d_vals = torch.from_numpy(vx).cuda()
 db = torch.from_numpy(b).cuda()
 ref = None
-for after, cap, single in ((0, 2048, 0), (2, 2048, 0), (2, 2048, 1), (2, 2560, 1)):
+for after, cap, single in ((0, 2048, 0), (2, 2048, 0), (2, 2048, 1), (2, 1024, 1)):
     f = HipFact(device=0)
     f.set_option("top_block_after", after); f.set_option("top_block_max", cap); f.set_option("top_block_single", single)
     f.set_matrix(SleqpMat(N, N, cp, ri, vx))
