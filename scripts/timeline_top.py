@@ -25,38 +25,37 @@ def build():
                   f"__device__ long long g_st[{NB} * 8];\n"
                   f"#define TRS(slot) if (threadIdx.x == 0) g_st[blockIdx.x * 8 + (slot)] = wall_clock64()\n"
                   "typedef double d4_t __attribute__((ext_vector_type(4)));", 1)
-    rep = [
-        # ordinary forward / backward items
+    def patch(text, reps):
+        for r in reps:
+            assert text.count(r[0]) == 1, (r[0], text.count(r[0]))
+            if len(r) == 2:
+                text = text.replace(r[0], r[1] + r[0], 1)
+            elif r[2] == "TAIL":
+                text = text.replace(r[0], r[0][:-2] + "  TRS(3);\n}", 1)
+            else:
+                text = text.replace(r[0], r[0] + r[2], 1)
+        return text
+
+    def segment(text, start, end, reps):
+        a, b = text.index(start), text.index(end)
+        return text[:a] + patch(text[a:b], reps) + text[b:]
+
+    s = segment(s, "__device__ __forceinline__ void dev_solve_fwd(", "__device__ __forceinline__ void dev_solve_bwd(", [
         ("  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here", "  TRS(1);\n"),
         ("  if (tid < rl) f[tid] = f0;\n  __syncthreads();", None, "\n  TRS(2);"),
-        ("      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n}", None, "TAIL"),
+        ("      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n}", None, "TAIL")])
+    s = segment(s, "__device__ __forceinline__ void dev_solve_bwd(", "// ---- top block (device_types.h: TopBlockIn)", [
         ("  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", "  TRS(1);\n"),
         ("  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();", None, "\n  TRS(2);"),
-        ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n}", None, "TAIL"),
-        ("  const int par = *epoch & 1;  // constant while anybody reads it", "  TRS(0);\n"),
-        # top forward
-        ("  // the slots the PREVIOUS launch exchanged through go back to the sentinel (this launch uses the other copy)", "  TRS(1);\n"),
+        ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n}", None, "TAIL")])
+    s = patch(s, [("  const int par = *epoch & 1;  // constant while anybody reads it", "  TRS(0);\n")])
+    # the top block as one product (dev_top_one): entry | prefetch issued | lists in LDS | gathered | posted
+    s = segment(s, "__device__ __forceinline__ void dev_top_one(", "// Z = X_T^T D_T^-1 X_T from the dense X_T", [
+        ("  if (tid < nr) {\n    sent_f64(ysol_prev + B.tpos[I.r0 + tid]);", "  TRS(1);\n"),
         ("  constexpr int GK = 6;", "  TRS(4);\n"),
-        ("      post_f64(B.xhatT2 + (size_t)par * nT + I.r0 + tid, s2);\n    }\n  }\n}", None, "TAIL"),
-        # top backward
-        ("  const double* __restrict__ xh = B.xhatT2 + (size_t)par * nT;", "  TRS(1);\n"),
-        ("      y[k] = s2;\n      post_f64(ysol + k, s2);\n    }\n  }\n}", None, "TAIL"),
-    ]
-    for r in rep:
-        assert s.count(r[0]) == 1, (r[0], s.count(r[0]))
-        if len(r) == 2:
-            s = s.replace(r[0], r[1] + r[0], 1)
-        elif r[2] == "TAIL":
-            s = s.replace(r[0], r[0][:-2] + "  TRS(3);\n}", 1)
-        else:
-            s = s.replace(r[0], r[0] + r[2], 1)
-    # "gathered" stamp of the top items: the barrier in front of the product
-    a = s.index("__device__ __forceinline__ void dev_top_fwd(")
-    b = s.index("// X_T = inv(L_TT), TOP_CB columns per workgroup")
-    seg = s[a:b]
-    assert seg.count("  __syncthreads();\n  double acc = 0.0;") == 2
-    seg = seg.replace("  __syncthreads();\n  double acc = 0.0;", "  __syncthreads();\n  TRS(2);\n  double acc = 0.0;")
-    s = s[:a] + seg + s[b:]
+        ("  __syncthreads();\n  double acc = 0.0;", None, "\n  TRS(2);"),
+        ("      y[k] = s2;\n      post_f64(ysol + k, s2);\n    }\n  }\n}", None, "TAIL")])
+    s = s.replace("  __syncthreads();\n  double acc = 0.0;\n  TRS(2);", "  __syncthreads();\n  TRS(2);\n  double acc = 0.0;")
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "kernels_solve.hip")
     t = open(h).read()
@@ -79,7 +78,7 @@ def run():
     J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
     lib = _lib.load()
     lib.hipfact_debug_trace_tree.argtypes = [C.c_void_p]
-    for after, cap in ((0, 2048), (2, 2048), (2, 2560)):
+    for after, cap in ((0, 2048), (2, 2048)):
         f = HipFact(device=0)
         f.set_option("use_graph", 0)
         f.set_option("refine_steps", 0)
@@ -99,15 +98,15 @@ def run():
         base = t[ntr:ntr + nfb, 0].min()  # (first forward item of this launch; slots of other blocks may hold older stamps)
         t = (t - base) / 100.0
         fw = t[ntr:ntr + nfb]
+        single = nT > 0 and bool(f.info("top_block_single"))
+        ntb = 0 if single else ntf
         tf = t[ntr + nfb:ntr + nfb + ntf]
-        tb = t[ntr + nfb + ntf:ntr + nfb + 2 * ntf]
-        bw = t[ntr + nfb + 2 * ntf:ntr + 2 * nfb + 2 * ntf]
-        print(f"== top_block_after {after} cap {cap}: nT {nT}, {ntf} top items per direction, {nfb} items below, rhs items {ntr}")
-        print(f"forward below: last posted {fw[:, 3].max():7.2f}   (last 12 items posted: {np.sort(fw[:, 3])[-12:].round(1)})")
-        if ntf:
+        bw = t[ntr + nfb + ntf + ntb:ntr + 2 * nfb + ntf + ntb]
+        print(f"== top_block_after {after} cap {cap}: nT {nT}, {ntf} top items, single product {single}, {nfb} items below, rhs items {ntr}")
+        print(f"forward below: first entry {fw[:, 0].min():7.2f} last posted {fw[:, 3].max():7.2f}   (last 12 items posted: {np.sort(fw[:, 3])[-12:].round(1)})")
+        if ntf and single:
             q = lambda a: " ".join(f"{v:7.2f}" for v in np.percentile(a, [0, 50, 100]))
-            print(f"top fwd: entry [{q(tf[:, 0])}] prefetch issued [{q(tf[:, 1])}] lists in LDS [{q(tf[:, 4])}] gathered [{q(tf[:, 2])}] posted [{q(tf[:, 3])}]")
-            print(f"top bwd: entry [{q(tb[:, 0])}] prefetch issued [{q(tb[:, 1])}] polled [{q(tb[:, 2])}] posted [{q(tb[:, 3])}]")
+            print(f"top items: entry [{q(tf[:, 0])}] prefetch issued [{q(tf[:, 1])}] lists in LDS [{q(tf[:, 4])}] gathered [{q(tf[:, 2])}] posted [{q(tf[:, 3])}]")
         print(f"backward below: first waited {bw[:, 2].min():7.2f} first posted {bw[:, 3].min():7.2f} last posted {bw[:, 3].max():7.2f}")
         print(f"(first 12 backward items: waited {bw[:12, 2].round(1)} posted {bw[:12, 3].round(1)})")
         f.free()
