@@ -827,7 +827,7 @@ def main():
     fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
     for _ in range(3):
         fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
-    fact.synchronize()
+    fact.check()
     t0 = time.perf_counter()
     for _ in range(nsolve):
         fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
@@ -835,8 +835,9 @@ def main():
     top_block["ms_per_solve_without"] = (time.perf_counter() - t0) / nsolve * 1e3
     fact.set_option("top_block_after", 2)
     fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
-    for _ in range(2):  # (the plan is new: its graphs - factorisation, checked / unchecked solves, with the top block - once, untimed)
-        step(12)
+    for _ in range(2):  # (the plan is new: its graphs - factorisation, checked / unchecked solves, with the top block - once, untimed;
+        step(12)        # and a synchronising look at the refinement verdict, which is what lets the following
+        fact.check()    # factorisations of this plan start without a correction pass in their solves)
     fact.synchronize()
 
     extras = {}
