@@ -789,14 +789,21 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
     // hub rows: adjacent to a large share of all rows - out of the dissection, ordered last
     if (prm.hub_tau > 0.0 && prm.ordering != 2) {
       const double thr = std::max((double)prm.hub_min, prm.hub_tau * std::sqrt((double)my));
-      int nh = 0;
-      for (int a = 0; a < my; ++a) nh += (double)(g.ptr[a + 1] - g.ptr[a]) > thr;
-      // (a graph in which every other row qualifies is simply dense: nothing to take out)
-      if (nh > 0 && nh <= std::max(64, my / 16)) {
+      std::vector<std::pair<int64_t, int>> cand;  // (-degree, row)
+      for (int a = 0; a < my; ++a)
+        if ((double)(g.ptr[a + 1] - g.ptr[a]) > thr) cand.push_back({-(g.ptr[a + 1] - g.ptr[a]), a});
+      // at most max(64, m / 8) of them, the best connected first (when a large share of all rows qualifies the graph
+      // is simply dense: taking the worst of them out still shortens the separators of the rest)
+      const size_t cap = (size_t)std::max(64, my / 8);
+      if (cand.size() > cap) {
+        std::partial_sort(cand.begin(), cand.begin() + (long)cap, cand.end());
+        cand.resize(cap);
+      }
+      if (!cand.empty()) {
         if (late_row.empty()) late_row.assign((size_t)my, 0);
-        for (int a = 0; a < my; ++a)
-          if ((double)(g.ptr[a + 1] - g.ptr[a]) > thr && !late_row[(size_t)a]) {
-            late_row[(size_t)a] = 1;
+        for (const auto& c : cand)
+          if (!late_row[(size_t)c.second]) {
+            late_row[(size_t)c.second] = 1;
             ++n_late_rows;
           }
       }
