@@ -896,13 +896,28 @@ def main():
                                            "dots | tests + z, r | projection with x update and r.g | beta + d), host looks at the "
                                            "control block every 8 iterations"}
         fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
+        lz_dev_its0 = fact.info("lz_device_iterations")
         t0 = time.perf_counter()
         _, _, its = fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=20)
         t_lzd = time.perf_counter() - t0
+        lz_dev_its = fact.info("lz_device_iterations")
+        fact.set_option("lz_device_loop", 0)
+        fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
+        t0 = time.perf_counter()
+        _, _, its_h = fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=20)
+        t_lzh = time.perf_counter() - t0
+        fact.set_option("lz_device_loop", 1)
         extras["eqp_lanczos_device"] = {"iterations": its, "ms_per_iteration": t_lzd * 1e3 / max(its, 1),
-                                        "note": "GLTR (what trlib runs) with the explicit Hessian in HBM: the tridiagonal "
-                                                "trust-region subproblem is solved on the host every iteration (two "
-                                                "synchronisations per iteration)"}
+                                        "device_iterations": lz_dev_its - lz_dev_its0,
+                                        "device_fallbacks": fact.info("lz_device_fallbacks"),
+                                        "ms_per_iteration_host_loop": t_lzh * 1e3 / max(its_h, 1),
+                                        "note": "GLTR (what trlib runs) with the explicit Hessian in HBM.  While the Lanczos "
+                                                "tridiagonal is positive definite and its Newton step interior the loop is "
+                                                "controlled on the device (pivot / step recurrences in a control block, 3 "
+                                                "launches per iteration: product + dot | recurrence | projection; the host "
+                                                "looks every 8 iterations and solves ONE tridiagonal trust-region problem at "
+                                                "the end); host_loop: one tridiagonal solve and one synchronisation per "
+                                                "iteration (lz_device_loop = 0, also what runs beyond the boundary)"}
         Hs = (Hl + Hl.T - sp.diags(Hl.diagonal())).tocsr()
         _, _, its = fact.tr_solve(lambda d: Hs @ d, grad, 1e6, method=1, stat_tol=1e-30, max_iter=3)
         t0 = time.perf_counter()

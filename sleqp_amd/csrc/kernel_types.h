@@ -83,5 +83,19 @@ struct CgCtl {
   int state;  // 0 running, 1 interior solution (|r.g| small), 2 boundary, 3 negative curvature, 4 iteration cap
   int stop, apply, it, max_iter, pad;
 };
+// Control block of the device-controlled phase of GLTR (krylov_device.inc): the LDL^T recurrence of the Lanczos
+// tridiagonal and the CG quantities that follow from it, O(1) per iteration
+struct LzCtl {
+  double tol, rad_sq, gamma0;
+  double gam_prev, gam_cur;  // gamma_{k-1}, gamma_k of the iteration in flight
+  double del_cur;            // delta_k of the iteration in flight
+  double piv, fsub;          // T = L D L^T: pivot d_{k-1} and the forward-substitution value f_{k-1}
+  double rho, s_nrm_sq, sp, p_nrm_sq;  // ||r||^2, ||s||^2, <s, p>, ||p||^2 of the equivalent CG iterate (M-norms)
+  int k;      // Lanczos iterations 0 .. k-1 are complete when `stop` is set
+  int stop;
+  int state;  // 0 running, 1 converged, 2 the interior solution left the trust region, 3 pivot <= 0 (T not positive
+              // definite), 5 iteration cap
+  int kmax;
+};
 
 }  // namespace hipfact

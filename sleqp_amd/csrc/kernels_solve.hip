@@ -62,6 +62,14 @@ INST_CG(4)
 INST_CG(16)
 INST_CG(64)
 #undef INST_CG
+#define INST_LZ(L)                                                                                                  \
+  template __global__ void k_lz_spmv_dot<L>(int, const LzCtl*, const int*, const int*, const double*, const int*,   \
+                                            const int*, const double*, const double*, double*, double*);
+INST_LZ(1)
+INST_LZ(4)
+INST_LZ(16)
+INST_LZ(64)
+#undef INST_LZ
 template __global__ void k_x_saddle<true>(int, int, const int*, const double*, const int*, const int*, SaddleMaps,
                                           const double*, const double*, double*, const int*, int*);
 template __global__ void k_x_saddle<false>(int, int, const int*, const double*, const int*, const int*, SaddleMaps,

@@ -1685,7 +1685,14 @@ def test_full_size_krylov_loops(fact):
     assert np.abs(A @ step).max() <= 1e-9 * anorm * max(1.0, np.abs(step).max())
     q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
     assert q(step) < 0.0
+    fact.set_option("lz_device_loop", 0)
+    lz_host, _, its_host = fact.tr_solve(Hd, g, 1e6, method=1, stat_tol=1e-3, max_iter=300)
+    fact.set_option("lz_device_loop", 1)
+    lzi = fact.info("lz_device_iterations")
     lz, _, its2 = fact.tr_solve(Hd, g, 1e6, method=1, stat_tol=1e-3, max_iter=300)
+    # (the whole run inside the trust region: every iteration on the device, the host solves ONE tridiagonal problem)
+    assert its2 == its_host and fact.info("lz_device_iterations") - lzi == its2 and fact.info("lz_device_fallbacks") == 0
+    assert rel_err(lz, lz_host) <= 1e-9
     # (both stop at stat_tol 1e-3 by their own tests: the iterates agree to that order, the model values much better)
     assert 0 < its2 < 300 and rel_err(lz, step) <= 2e-4 and abs(q(lz) - q(step)) <= 1e-7 * abs(q(step))
     # trust region active
@@ -1825,6 +1832,7 @@ def test_krylov_loops_with_dense_jacobian_columns(fact, method, mode):
         assert 0 < its_ref < 100
         for device_loop in (1, 0):
             fact.set_option("cg_device_loop", device_loop)
+            fact.set_option("lz_device_loop", device_loop)
             step, dual, its = fact.tr_solve(H, g, radius, method=method, stat_tol=tol, max_iter=200)
             if method == 0:
                 assert abs(its - its_ref) <= 1, (its, its_ref)
@@ -1838,6 +1846,60 @@ def test_krylov_loops_with_dense_jacobian_columns(fact, method, mode):
                 assert rel_err(step, want) <= ((5e-5 if method == 1 else 1e-6) if radius > 100 else 1e-7), (radius, device_loop)
             assert np.abs(J @ step).max() <= 1e-9 * max(1.0, np.abs(step).max()) * abs(J).sum(axis=1).max()
             assert np.linalg.norm(step) <= radius * (1 + 1e-10)
+    H.free()
+
+
+@pytest.mark.parametrize("kind", ["positive_definite", "indefinite"])
+def test_gltr_device_phase_matches_host_loop(fact, kind):
+    """GLTR with the iterations of the positive definite / interior phase controlled on the device (krylov_device.inc:
+    pivot and step recurrences of the Lanczos tridiagonal in a control block, three launches per iteration, the host
+    looks every 8 iterations) against the host-driven loop (trlib's iteration, one tridiagonal trust-region solve per
+    iteration): same iteration count, step and multiplier when the phase ends by convergence, by the iteration cap
+    (at, one below and one above the chunk length; caps 1 and 2), by leaving the trust region or by an indefinite
+    tridiagonal - the last two hand the loop over to the host in the middle of the Krylov space."""
+    from sleqp_amd.fact import SpMat, StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 1500, 700
+    J = synth.banded_jacobian(n, m, 10, 80, 17)
+    rng = np.random.default_rng(19)
+    vi, ci, W = _ws(n, m, rng, 1.0, 0.0)
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    B = sp.random(n, n, density=3.0 / n, random_state=3)
+    shift = 0.5 if kind == "positive_definite" else -0.4
+    HL = sp.tril(B @ B.T + shift * sp.eye(n), format="csc")
+    HL.sort_indices()
+    H = SpMat(fact, SleqpMat.from_scipy(HL))
+    Hs = (HL + HL.T - sp.diags(HL.diagonal())).tocsr()
+    q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
+    g = rng.standard_normal(n)
+    big = 1e4 if kind == "positive_definite" else 40.0
+    fact.set_option("lz_device_loop", 0)
+    ref, _, _ = fact.tr_solve(H, g, big, method=1, stat_tol=1e-9, max_iter=400)
+    nr = np.linalg.norm(ref)
+    device_iterations = 0
+    for radius, tol, cap in ((big, 1e-4, 400), (big, 1e-9, 400), (0.3 * nr, 1e-7, 400), (0.999 * nr, 1e-9, 400),
+                             (big, 1e-30, 7), (big, 1e-30, 8), (big, 1e-30, 9), (big, 1e-30, 17), (big, 1e-30, 1), (big, 1e-30, 2)):
+        out = {}
+        for dev in (0, 1):
+            fact.set_option("lz_device_loop", dev)
+            i0 = fact.info("lz_device_iterations")
+            out[dev] = fact.tr_solve(H, g, radius, method=1, stat_tol=tol, max_iter=cap) + (fact.info("lz_device_iterations") - i0,)
+        (s0, d0, it0, _), (s1, d1, it1, dits) = out[0], out[1]
+        assert it1 == it0 and 0 < it0 <= cap, (radius, tol, cap, it0, it1)
+        assert rel_err(s1, s0) <= 1e-9, (radius, tol, cap)
+        assert abs(d1 - d0) <= 1e-9 * max(1.0, abs(d0))
+        assert abs(q(s1) - q(s0)) <= 1e-10 * abs(q(s0))
+        assert np.linalg.norm(s1) <= radius * (1 + 1e-10)
+        assert np.abs(J @ s1).max() <= 1e-9 * max(1.0, np.abs(s1).max()) * abs(J).sum(axis=1).max()
+        assert dits <= it1
+        if cap >= 2:
+            assert dits >= 1  # (the phase ran; with cap 1 there is nothing to hand to the device)
+        if kind == "positive_definite" and radius == big and cap >= 2:
+            assert dits == it1  # (never left: every iteration on the device)
+        device_iterations += dits
+    assert device_iterations > 0 and fact.info("lz_device_fallbacks") == 0
     H.free()
 
 
