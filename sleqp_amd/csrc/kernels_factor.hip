@@ -55,9 +55,9 @@ INST_MVALS(long long, false)
 #undef INST_MVALS
 #define INST_FRONT(CH)                                                                                              \
   template __global__ void k_front_pivot<CH>(const FrontItem*, double*, double*, int*, const int*, const int*,     \
-                                             const PullDesc*, int);                                                 \
+                                             const PullDesc*, int, const unsigned*);                                \
   template __global__ void k_front_panel<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
-                                             const PullDesc*, int);                                                 \
+                                             const PullDesc*, int, const unsigned*);                                \
   template __global__ void k_front_schur<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
                                              const PullDesc*, int);
 INST_FRONT(true)

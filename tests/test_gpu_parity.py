@@ -984,6 +984,38 @@ def test_determinism(fact):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+def test_assign_mode_panels_give_the_same_bits(fact):
+    """`assign_panels`: no zero fill of the factor arena - the kernels that enter a front read its panel through a bit
+    mask of M's entries and ignore what the previous factorisation left there.  Same values in the same order: the
+    solution must be bit for bit the one of the cleared arena, also on the second and third factorisation (when the
+    arena holds the previous factor) and with other values."""
+    from bench import make_problem
+    from sleqp_amd.sparse import SleqpMat
+
+    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    vx2 = np.array(vx, copy=True)
+    n = J.shape[1]
+    rng = np.random.default_rng(21)
+    off = np.ones(len(vx2), dtype=bool)
+    off[np.asarray(cp[:n])] = False  # (the unit diagonal stays)
+    vx2[off] *= 1.0 + 0.3 * rng.standard_normal(int(off.sum()))
+    outs = {}
+    for mode in (0, 1):
+        fact.set_option("assign_panels", mode)
+        got = []
+        for vals in (vx, vx2, vx):
+            fact.set_matrix(SleqpMat(N, N, cp, ri, vals))
+            if mode == 1:
+                assert fact.info("assign_panels") == 1  # (every level of this tree pulls its children)
+            fact.solve(b)
+            got.append(fact.solution_raw(0, N))
+        outs[mode] = got
+    for a, c in zip(outs[0], outs[1]):
+        assert np.array_equal(a, c)
+    assert not np.array_equal(outs[0][0], outs[0][1])
+    fact.set_option("assign_panels", 0)
+
+
 @pytest.mark.parametrize("kind,n,m", [("b", 6000, 3000), ("u", 1500, 700)])
 def test_pull_and_scatter_extend_add_agree_bitwise(fact, kind, n, m):
     """The two extend-add paths (separate assembly kernel / gather inside the pivot, panel and
