@@ -1931,6 +1931,14 @@ def test_gltr_device_phase_matches_host_loop(fact, kind):
         if kind == "positive_definite" and radius == big and cap >= 2:
             assert dits == it1  # (never left: every iteration on the device)
         device_iterations += dits
+        # option: the product H y_{k+1} inside the projection's launch (workgroups behind the x update that poll y)
+        fact.set_option("lz_fold_product", 1)
+        f0 = fact.info("lz_folded_products")
+        s2, d2, it2 = fact.tr_solve(H, g, radius, method=1, stat_tol=tol, max_iter=cap)
+        fact.set_option("lz_fold_product", 0)
+        assert it2 == it0 and rel_err(s2, s0) <= 1e-9 and abs(d2 - d0) <= 1e-9 * max(1.0, abs(d0))
+        if dits >= 2:
+            assert fact.info("lz_folded_products") > f0
     assert device_iterations > 0 and fact.info("lz_device_fallbacks") == 0
     H.free()
 
