@@ -13,6 +13,7 @@
 #include "graph.h"
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cassert>
 #include <cstdint>
@@ -606,6 +607,8 @@ struct NDState {
     }
     const int id = ++stamp;
     for (int v : verts) inset[v] = id;
+    const auto t_rec0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rec0).count(); };
 
     std::vector<int> order, lev_ptr;
     // connected components: only looked for when the first sweep below does not reach every vertex
@@ -686,6 +689,7 @@ struct NDState {
       fresh = false;
     }
     if (!fresh) bfs(root, id, order, lev_ptr);
+    const double t_bfs = since();
     const int nlev = (int)lev_ptr.size() - 1;
     if (nlev < 3) {
       leaf(verts, off);
@@ -751,7 +755,9 @@ struct NDState {
     std::vector<int>().swap(verts);
     std::vector<int>().swap(order);
     const int nl = (int)left.size(), nr = (int)right.size();
-    if (nd_debug) fprintf(stderr, "nd depth %d k %d sep %zu left %d right %d nlev %d\n", depth, k, sep.size(), nl, nr, nlev);
+    if (nd_debug && depth <= 3)
+      fprintf(stderr, "nd depth %d k %d sep %zu left %d right %d nlev %d: sweeps %.2f ms, cut %.2f ms\n", depth, k, sep.size(), nl, nr,
+              nlev, t_bfs, since() - t_bfs);
     for (size_t t = 0; t < sep.size(); ++t) perm[off + nl + nr + t] = sep[t];
     if (std::min(nl, nr) >= 2048 && threads_running.load() < max_threads) {
       ++threads_running;
@@ -774,8 +780,13 @@ void nd_order(const Graph& g, const NDParams& p, std::vector<int>& perm) {
   st.max_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
   std::vector<int> all(g.n);
   std::iota(all.begin(), all.end(), 0);
+  const auto t0 = std::chrono::steady_clock::now();
   st.rec(std::move(all), 0);
+  const auto t1 = std::chrono::steady_clock::now();
   st.run_leaves();
+  if (st.nd_debug)
+    fprintf(stderr, "nd: dissection %.2f ms, %zu leaves ordered in %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            st.leaves.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   assert((int)perm.size() == g.n);
 }
 
