@@ -82,5 +82,52 @@ def main():
     Hd.free()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "matrix_free"):
     main()
+
+
+def matrix_free():
+    """The matrix-free iteration (Hessian product on the host through the callback): the callback's own time beside
+    the time per iteration."""
+    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
+    m, n = J.shape
+    fact = HipFact()
+    fact.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    for _ in range(4):
+        fact.solve(b)
+    fact.check()
+    rng = np.random.default_rng(7)
+    g = rng.standard_normal(n)
+    Hl = sp.diags([np.full(n, 2.0)] + [rng.standard_normal(n - k) * 0.1 for k in range(1, 6)], [0, -1, -2, -3, -4, -5], format="csc")
+    Hs = (Hl + Hl.T - sp.diags(Hl.diagonal())).tocsr()
+    d = rng.standard_normal(n)
+    for _ in range(5):
+        Hs @ d
+    t0 = time.perf_counter()
+    for _ in range(50):
+        Hs @ d
+    t_cb = (time.perf_counter() - t0) / 50
+    spent = [0.0, 0]
+
+    def prod(v):
+        t = time.perf_counter()
+        out = Hs @ v
+        spent[0] += time.perf_counter() - t
+        spent[1] += 1
+        return out
+
+    for dev in (1, 0, 1, 0, 1, 0, 1, 0):
+        fact.set_option("lz_device_loop", dev)
+        fact.tr_solve(prod, g, 1e6, method=1, stat_tol=1e-30, max_iter=20)
+        spent[0], spent[1] = 0.0, 0
+        t0 = time.perf_counter()
+        s, dual, its = fact.tr_solve(prod, g, 1e6, method=1, stat_tol=1e-30, max_iter=20)
+        dt = time.perf_counter() - t0
+        print(f"matrix-free (device phase option {dev}): {its} iterations, {dt * 1e3 / its:.4f} ms per iteration; the callback itself "
+              f"{spent[0] * 1e3 / max(spent[1], 1):.4f} ms x {spent[1]} calls (scipy product alone {t_cb * 1e3:.4f} ms); |s| {np.linalg.norm(s):.8e}; "
+              f"dataflow fallbacks {int(fact.info('dataflow_fallbacks'))}, refined solves {int(fact.info('num_refined'))}, solves {int(fact.info('num_solve'))}",
+              flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "matrix_free":
+    matrix_free()
