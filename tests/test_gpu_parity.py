@@ -1455,6 +1455,21 @@ def test_residual_checked_on_every_kth_solve_only(fact):
         assert np.array_equal(a, b_)
         assert scaled_residual(K, a, rh) <= 1e-12
     fact.set_option("refine_check_every", 8)
+    # the interval grows while the checks keep passing (refine_check_backoff 2, refine_check_max 64): solves 1, 9, 25,
+    # 57, 121, 185 of a factorisation are checked; a new factorisation starts over at 8; backoff 1 keeps the interval
+    for backoff, want in ((2, 6), (1, 25)):
+        fact.set_option("refine_check_backoff", backoff)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        c0 = fact.info("num_checked")
+        for i in range(200):
+            fact.solve(rhs[i % len(rhs)])
+        last = fact.solution_raw(0, N)
+        assert fact.info("num_checked") - c0 == want, (backoff, fact.info("num_checked") - c0)
+        assert np.array_equal(last, outs[1][199 % len(rhs)])
+        assert fact.info("refine_check_interval") == (64 if backoff == 2 else 8)
+    fact.set_option("refine_check_backoff", 2)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("refine_check_interval") == 8
 
 
 def test_dense_chain_levels_as_small_dataflow_launches(fact):
