@@ -1,0 +1,253 @@
+"""Randomised parity sweep: working sets of random Jacobians (banded / uniform, with dense columns, dense rows, active
+bounds, partial working sets) through hipfact against an independent sparse LU of K (scipy SuperLU) - factor + solve,
+a second right-hand side, a refactorisation with other values, and the trust-region solvers (Steihaug and GLTR, device
+and host loops) against each other and against the KKT conditions of the projected problem.
+
+    gpurun -- python scripts/fuzz_parity.py [cases] [seed]
+
+The oracle is only the checker here (scipy), nothing of it is in the product path.  Prints one line per failure and a
+summary; exit code 1 if anything failed.
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from sleqp_amd import synth  # noqa: E402
+from sleqp_amd.fact import HipFact, SpMat, StandardAugJac  # noqa: E402
+from sleqp_amd.sparse import SleqpMat, SleqpVec  # noqa: E402
+
+
+LAST_TAG = [""]
+
+
+def scaled_residual(K, z, b):
+    r = K @ z - b
+    return float(np.abs(r).max() / (abs(K).sum(axis=1).max() * max(np.abs(z).max(), 1e-300) + np.abs(b).max() + 1e-300))
+
+
+def working_set(n, m, rng, row_frac, bound_frac):
+    vi = np.full(n, -1, dtype=np.int32)
+    av = np.sort(rng.choice(n, int(round(bound_frac * n)), replace=False))
+    vi[av] = np.arange(av.size)
+    ci = np.full(m, -1, dtype=np.int32)
+    ac = np.sort(rng.choice(m, max(1, int(round(row_frac * m))), replace=False))
+    ci[ac] = av.size + np.arange(ac.size)
+    return vi, ci
+
+
+def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
+    """One random case; returns (tag, list of failures) or (tag, "skipped ...").  tol: stat_tol of the trust-region
+    solvers (default: FUZZ_TOL or 1e-4)."""
+    if tol is None:
+        tol = float(os.environ.get("FUZZ_TOL", "1e-4"))
+    kind = rng.choice(["banded", "uniform"])
+    n = int(rng.choice([40, 150, 600, 1500, 4000, 12000]))
+    m = max(1, int(n * rng.choice([0.2, 0.5, 0.8])))
+    if kind == "banded":
+        J = synth.banded_jacobian(n, m, int(min(rng.integers(3, 14), n)), int(min(rng.integers(20, 200), n)), int(rng.integers(1 << 30)))
+    else:
+        if n > 4000:
+            n, m = 1500, 700
+        J = synth.uniform_jacobian(n, m, int(min(rng.integers(2, 6), n)), int(rng.integers(1 << 30)))
+    extra = rng.choice(["none", "none", "dense_cols", "dense_rows", "both", "many_cols"])
+    if extra in ("dense_cols", "both"):
+        J, _ = synth.with_dense_columns(J, int(rng.integers(1, 6)), int(rng.integers(1 << 30)), frac=float(rng.choice([1.0, 0.6])))
+    if extra == "many_cols":
+        J, _ = synth.with_dense_columns(J, int(min(n // 2, rng.integers(20, 90))), int(rng.integers(1 << 30)), entries=int(min(m, rng.integers(30, 200))))
+    if extra in ("dense_rows", "both"):
+        J, _ = synth.with_dense_rows(J, int(rng.integers(1, 3)), int(rng.integers(1 << 30)))
+    J = sp.csc_matrix(J)
+    J.sort_indices()
+    bound_frac = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+    row_frac = float(rng.choice([1.0, 1.0, 0.7, 0.3]))
+    # (keep the working set's rows independent: no more rows + bounds than variables)
+    while int(round(bound_frac * n)) + int(round(row_frac * m)) > n - 1 and row_frac > 0.05:
+        row_frac *= 0.7
+    vi, ci = working_set(n, m, rng, row_frac, bound_frac)
+    tag = f"case {idx}: {kind} n={n} m={J.shape[0]} extra={extra} rows={row_frac:.2f} bounds={bound_frac:.2f}"
+    mode = int(rng.choice([1, 1, 2]))
+    tag += f" dense_mode={mode}"
+    LAST_TAG[0] = tag
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("running", tag, file=sys.stderr, flush=True)
+    # the matrix the reference would assemble, for the independent check
+    N, kc, kr, kd = synth.kkt_lower_from_jacobian(J, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd).tocsc()
+    # (SuperLU has been seen to crash instead of reporting an exactly singular matrix: those are caught before it)
+    from scipy.sparse.csgraph import structural_rank
+
+    if structural_rank(K) < N or (N <= 500 and np.linalg.matrix_rank(K.toarray()) < N):
+        return tag, "skipped (singular working set)"
+    try:
+        lu = spla.splu(K)
+    except RuntimeError:
+        return tag, "skipped (singular working set)"
+    cond_proxy = np.abs(lu.U.diagonal()).max() / max(np.abs(lu.U.diagonal()).min(), 1e-300)
+    if not np.isfinite(cond_proxy) or cond_proxy > 1e10:
+        return tag, "skipped (ill conditioned)"
+    fact.set_option("dense_mode", mode)
+    for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # e.g. FUZZ_OPTS=xupd_fused=0,top_block_single=0
+        fact.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+    aug = StandardAugJac(n, fact)
+    aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+    errs = []
+    for rep in range(2):
+        b = rng.standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        want = lu.solve(b)
+        res = scaled_residual(K, z, b)
+        rel = float(np.linalg.norm(z - want) / max(np.linalg.norm(want), 1e-300))
+        # (the forward error is the condition's doing: SuperLU's own answer is no better)
+        if not (res <= 1e-11) or not (rel <= max(1e-6, 1e-13 * cond_proxy)):
+            errs.append(f"solve {rep}: scaled residual {res:.2e}, rel diff vs SuperLU {rel:.2e}")
+    for rep in range(int(os.environ.get("FUZZ_EXTRA_SOLVES", "0"))):
+        b = rng.standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"   extra solve {rep}: scaled residual {scaled_residual(K, z, b):.2e}, top block active {int(fact.info('top_block_active'))} "
+                  f"cols {int(fact.info('top_block_cols'))} below {int(fact.info('top_block_below'))} levels {int(fact.info('nlevels'))} "
+                  f"fronts {int(fact.info('nsuper'))} late rows {int(fact.info('late_rows'))}", file=sys.stderr, flush=True)
+    # the plain vtable boundary with the assembled K (row dictionary behind it)
+    f2 = HipFact()
+    f2.set_option("dense_mode", mode)
+    f2.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    b = rng.standard_normal(N)
+    f2.solve(b)
+    z2 = f2.solution_raw(0, N)
+    res2 = scaled_residual(K, z2, b)
+    if not (res2 <= 1e-11):
+        errs.append(f"vtable boundary: scaled residual {res2:.2e}")
+    # other values, same pattern
+    kd2 = np.array(kd, copy=True)
+    off = np.ones(len(kd2), dtype=bool)
+    off[np.asarray(kc[:n])] = False
+    unit = np.zeros(len(kd2), dtype=bool)
+    if (vi >= 0).any():
+        # the unit entries of the bound rows stay 1 (the dictionary recognises bound rows by them)
+        Kl = sp.csc_matrix((np.arange(len(kd2)), kr, kc), shape=(N, N))
+        for j in np.nonzero(vi >= 0)[0]:
+            col = slice(kc[j], kc[j + 1])
+            rows = np.asarray(kr[col])
+            unit[np.arange(kc[j], kc[j + 1])[rows == n + vi[j]]] = True
+        del Kl
+    chg = off & ~unit
+    kd2[chg] *= 1.0 + 0.2 * rng.standard_normal(int(chg.sum()))
+    K2 = synth.kkt_full_matrix(N, kc, kr, kd2).tocsc()
+    f2.set_matrix(SleqpMat(N, N, kc, kr, kd2))
+    f2.solve(b)
+    z3 = f2.solution_raw(0, N)
+    res3 = scaled_residual(K2, z3, b)
+    if not (res3 <= 1e-10):
+        errs.append(f"vtable boundary, other values: scaled residual {res3:.2e}")
+    del f2
+    # trust-region solvers on the null space of the working set
+    W = int((vi >= 0).sum() + (ci >= 0).sum())
+    if W < n and n >= 40:
+        B = sp.random(n, n, density=min(1.0, 3.0 / n), random_state=int(rng.integers(1 << 30)))
+        shift = float(rng.choice([0.5, 0.5, -0.3]))
+        HL = sp.tril(B @ B.T + shift * sp.eye(n), format="csc")
+        HL.sort_indices()
+        H = SpMat(fact, SleqpMat.from_scipy(HL))
+        Hs = (HL + HL.T - sp.diags(HL.diagonal())).tocsr()
+        g = rng.standard_normal(n)
+        q = lambda s_: float(g @ s_ + 0.5 * s_ @ (Hs @ s_))
+        radius = float(rng.choice([1e4, 5.0, 0.5])) if shift > 0 else float(rng.choice([5.0, 0.5]))
+        # rows of the working set in x space: bounds (unit rows) and constraint rows
+        rows = []
+        if (vi >= 0).any():
+            rows.append(sp.csr_matrix((np.ones(int((vi >= 0).sum())), (np.arange(int((vi >= 0).sum())), np.nonzero(vi >= 0)[0])), shape=(int((vi >= 0).sum()), n)))
+        rows.append(J.tocsr()[np.nonzero(ci >= 0)[0], :])
+        A = sp.vstack(rows).tocsr()
+        anorm = max(abs(A).sum(axis=1).max(), 1.0)
+        if os.environ.get("FUZZ_VERBOSE"):
+            # reference Lanczos coefficients in numpy (dense projection)
+            Ad = A.toarray()
+            Pm = np.eye(n) - Ad.T @ np.linalg.solve(Ad @ Ad.T, Ad)
+            t = g.copy(); y = Pm @ t; gam = [np.sqrt(t @ y)]; tprev = None; tcur = y.copy(); dl = []
+            for k in range(4):
+                qk = tcur / gam[k]
+                Hq = Hs @ qk
+                dl.append(qk @ Hq)
+                tn = Hq - dl[k] / gam[k] * tcur - (gam[k] / gam[k - 1] * tprev if k > 0 else 0.0)
+                yn = Pm @ tn
+                gam.append(np.sqrt(max(tn @ yn, 0.0)))
+                tprev, tcur = tcur, yn
+            print("   numpy Lanczos: delta", dl, "gamma", gam, file=sys.stderr, flush=True)
+        out = {}
+        for name, method, opt, val in (("gltr_dev", 1, "lz_device_loop", 1), ("gltr_host", 1, "lz_device_loop", 0),
+                                       ("cg_dev", 0, "cg_device_loop", 1), ("cg_host", 0, "cg_device_loop", 0)):
+            try:
+                fact.set_option(opt, val)
+            except Exception:  # noqa: BLE001  (an older library without the option)
+                pass
+            # (the reference's interior test of CG is absolute, |r.g| < (1e-2 stat_tol)^2: 1e-12 here, above the rounding
+            # level of r.g)
+            s, dual, its = fact.tr_solve(H, g, radius, method=method, stat_tol=tol, max_iter=300)
+            out[name] = (s, dual, its)
+            if os.environ.get("FUZZ_VERBOSE"):
+                print(f"   {name}: its {its} dual {dual:.6e} |s| {np.linalg.norm(s):.8e} q {q(s):.10e} radius {radius} shift {shift}", file=sys.stderr, flush=True)
+            if name.split("_")[0] not in krylov_checks:
+                continue
+            feas = float(np.abs(A @ s).max() / (anorm * max(np.abs(s).max(), 1.0)))
+            if not (feas <= 1e-8):
+                errs.append(f"{name}: step leaves the null space ({feas:.2e})")
+            if not (np.linalg.norm(s) <= radius * (1 + 1e-8)):
+                errs.append(f"{name}: step outside the trust region")
+            if not (q(s) <= 1e-12 * abs(q(s))):
+                errs.append(f"{name}: no model decrease ({q(s):.3e})")
+        try:
+            fact.set_option("lz_device_loop", 1)
+        except Exception:  # noqa: BLE001
+            pass
+        fact.set_option("cg_device_loop", 1)
+        (sa, da, ia), (sb, db, ib) = out["gltr_dev"], out["gltr_host"]
+        # (one iteration more or less where the convergence test is met to rounding is not a difference)
+        if abs(ia - ib) > 1 or np.linalg.norm(sa - sb) > 1e-6 * max(np.linalg.norm(sb), 1e-300) or abs(da - db) > 1e-6 * max(1.0, abs(db)):
+            errs.append(f"GLTR device phase vs host loop: its {ia}/{ib}, rel diff {np.linalg.norm(sa - sb) / max(np.linalg.norm(sb), 1e-300):.2e}, dual {da:.6e}/{db:.6e}")
+        (sa, da, ia), (sb, db, ib) = out["cg_dev"], out["cg_host"]
+        if "cg" in krylov_checks and (abs(ia - ib) > 1 or np.linalg.norm(sa - sb) > 1e-5 * max(np.linalg.norm(sb), 1e-300)):
+            errs.append(f"CG device loop vs host loop: its {ia}/{ib}, rel diff {np.linalg.norm(sa - sb) / max(np.linalg.norm(sb), 1e-300):.2e}")
+        # GLTR minimises over the whole Krylov space: at least as good as Steihaug's point
+        if "cg" in krylov_checks and q(out["gltr_dev"][0]) > q(out["cg_dev"][0]) + 1e-6 * abs(q(out["cg_dev"][0])):
+            errs.append(f"GLTR model value {q(out['gltr_dev'][0]):.8e} worse than CG {q(out['cg_dev'][0]):.8e}")
+        H.free()
+    return tag, errs
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # one case again (every case has a generator of its own)
+    fact = HipFact()
+    failed = skipped = 0
+    for idx in range(cases):
+        if only >= 0 and idx != only:
+            continue
+        rng = np.random.default_rng([seed, idx])
+        try:
+            tag, res = one_case(fact, rng, idx)
+        except Exception as e:  # noqa: BLE001
+            tag, res = f"case {idx} ({LAST_TAG[0]})", [f"exception {type(e).__name__}: {e}", traceback.format_exc(limit=3)]
+            fact = HipFact()
+        if isinstance(res, str):
+            skipped += 1
+            continue
+        if res:
+            failed += 1
+            print(tag, flush=True)
+            for r in res:
+                print("   ", r, flush=True)
+    print(f"{cases} cases (seed {seed}): {failed} failed, {skipped} skipped", flush=True)
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()

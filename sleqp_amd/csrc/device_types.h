@@ -177,6 +177,11 @@ struct TopBlockIn {
   double* __restrict__ tT2;           // the same for the rows of the right-hand side t that belong to T ...
   int ntr;                            // ... formed by the FIRST ntr workgroups of the launch (64 rows each; 0: t is in y)
   int single;                         // 1: ONE product y_T = Z f_T with Z = X_T^T D_T^-1 X_T (= inv(S_T)); XTf holds the rows of Z, ntb = 0
+  // single product: how many items of THIS launch have gathered f_T (two counters, by launch parity; item 0 clears
+  // the other one).  Every item reads every update vector that reaches T, and a front below T turns around as soon as
+  // the rows of y_T it needs are posted - by ONE item, while another may not have gathered yet: the backward items
+  // put their update slots back to the sentinel only once all ntf items have read them.
+  unsigned int* __restrict__ gathered2;
 };
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
