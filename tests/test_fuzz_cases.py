@@ -27,6 +27,9 @@ FOUND = [
     (6, 73, 1e-4, "late elimination: A_s nearly rank deficient in floating point (pivots spread over 30 decades, no "
                   "zero pivot): factored again with every column in S"),
     (6, 101, 1e-4, "the same, all rows in the working set"),
+    (9, 60, 1e-4, "the same with pivots over 10 decades only: a probe solve stalls, factored again with every column in S"),
+    (8, 38, 1e-4, "projected CG lost the null space on an ill-conditioned working set (host and device loop alike): r is "
+                  "replaced by its projection before B d is added"),
 ]
 
 
@@ -37,9 +40,10 @@ def test_cases_found_by_the_sweep(seed, idx, tol, what):
 
     fz = _fuzz()
     fact = HipFact()
-    # (the projected CG of the reference loses the null space on ill-conditioned working sets at tight tolerances, on the
-    # host and on the device alike: its checks are left to the sweep below at its own tolerance)
-    tag, res = fz.one_case(fact, np.random.default_rng([seed, idx]), idx, tol=tol, krylov_checks=("gltr",))
+    # (at tolerances below the rounding level of r.g the reference's absolute interior test of the projected CG is never
+    # met and the iteration wanders at noise level: its checks are made at the sweep's own tolerance only)
+    tag, res = fz.one_case(fact, np.random.default_rng([seed, idx]), idx, tol=tol,
+                           krylov_checks=("gltr", "cg") if tol >= 1e-4 else ("gltr",))
     assert not isinstance(res, str), (tag, res)
     assert res == [], (tag, what, res)
     assert fact.info("dataflow_fallbacks") == 0
