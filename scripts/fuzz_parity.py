@@ -24,6 +24,7 @@ from sleqp_amd.sparse import SleqpMat, SleqpVec  # noqa: E402
 
 
 LAST_TAG = [""]
+STEPS = [0]  # working sets of the sequence mode that were factored and checked
 
 
 def scaled_residual(K, z, b):
@@ -222,6 +223,103 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
     return tag, errs
 
 
+def sequence_case(rng, idx):
+    """A run of working sets of ONE Jacobian (rows and bounds entering and leaving) through both boundaries - the plain
+    vtable (K assembled on the host, row dictionary and superset plan behind hipfact_set_matrix) and the AugJac mirror
+    (device assembly) - with min-norm, least-squares and projection solves against dense references."""
+    kind = rng.choice(["banded", "uniform"])
+    n = int(rng.choice([60, 300, 1200, 3000]))
+    m = max(2, int(n * rng.choice([0.3, 0.6])))
+    if kind == "banded":
+        J = synth.banded_jacobian(n, m, int(min(rng.integers(3, 10), n)), int(min(rng.integers(20, 120), n)), int(rng.integers(1 << 30)))
+    else:
+        J = synth.uniform_jacobian(n, m, int(min(rng.integers(2, 5), n)), int(rng.integers(1 << 30)))
+    extra = rng.choice(["none", "dense_cols", "dense_rows"])
+    if extra == "dense_cols":
+        J, _ = synth.with_dense_columns(J, int(rng.integers(1, 5)), int(rng.integers(1 << 30)))
+    if extra == "dense_rows":
+        J, _ = synth.with_dense_rows(J, 1, int(rng.integers(1 << 30)))
+    J = sp.csc_matrix(J)
+    J.sort_indices()
+    m = J.shape[0]
+    tag = f"sequence {idx}: {kind} n={n} m={m} extra={extra}"
+    LAST_TAG[0] = tag
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("running", tag, file=sys.stderr, flush=True)
+    fv = HipFact()   # plain vtable
+    fa = HipFact()   # AugJac mirror
+    aug = StandardAugJac(n, fa)
+    rows_on = rng.random(m) < 0.6
+    bnd_on = rng.random(n) < 0.05
+    errs = []
+    from scipy.sparse.csgraph import structural_rank
+
+    for step in range(6):
+        # a few rows / bounds enter and leave
+        flip = rng.random(m) < 0.04
+        rows_on ^= flip
+        flipb = rng.random(n) < 0.01
+        bnd_on ^= flipb
+        if rows_on.sum() + bnd_on.sum() > n - 2:
+            rows_on[np.nonzero(rows_on)[0][: int(rows_on.sum() + bnd_on.sum() - (n - 2))]] = False
+        vi = np.full(n, -1, dtype=np.int32)
+        av = np.nonzero(bnd_on)[0]
+        vi[av] = np.arange(av.size)
+        ci = np.full(m, -1, dtype=np.int32)
+        ac = np.nonzero(rows_on)[0]
+        ci[ac] = av.size + np.arange(ac.size)
+        Jv = sp.csc_matrix((J.data * (1.0 + 0.1 * rng.standard_normal(J.nnz)), J.indices, J.indptr), shape=J.shape)
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(Jv, vi, ci)
+        K = synth.kkt_full_matrix(N, kc, kr, kd).tocsc()
+        if structural_rank(K) < N or (N <= 500 and np.linalg.matrix_rank(K.toarray()) < N):
+            continue
+        try:
+            lu = spla.splu(K)
+        except RuntimeError:
+            continue
+        dg = np.abs(lu.U.diagonal())
+        if not np.isfinite(dg.max() / max(dg.min(), 1e-300)) or dg.max() / max(dg.min(), 1e-300) > 1e9:
+            continue
+        W = N - n
+        STEPS[0] += 1
+        b = rng.standard_normal(N)
+        for name, f in (("vtable", fv), ("augjac", fa)):
+            if name == "vtable":
+                f.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            else:
+                aug.set_iterate(SleqpMat.from_scipy(Jv), vi, ci)
+            f.solve(b)
+            z = f.solution_raw(0, N)
+            res = scaled_residual(K, z, b)
+            if not (res <= 1e-11):
+                errs.append(f"step {step} {name}: scaled residual {res:.2e}")
+        # the three AugJac solves against the dense formulas
+        rows = []
+        if av.size:
+            rows.append(sp.csr_matrix((np.ones(av.size), (np.arange(av.size), av)), shape=(av.size, n)))
+        rows.append(Jv.tocsr()[ac, :])
+        A = sp.vstack(rows).toarray() if n <= 1200 else None
+        if A is not None and W > 0:
+            AAt = A @ A.T
+            rhs_w = rng.standard_normal(W)
+            want = A.T @ np.linalg.solve(AAt, rhs_w)
+            got = aug.solve_min_norm(SleqpVec.from_raw(rhs_w)).to_raw()
+            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+                errs.append(f"step {step}: min-norm solve rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
+            rhs_n = rng.standard_normal(n)
+            want = np.linalg.solve(AAt, A @ rhs_n)
+            got = aug.solve_lsq(SleqpVec.from_raw(rhs_n)).to_raw()
+            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+                errs.append(f"step {step}: least-squares solve rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
+            want = rhs_n - A.T @ np.linalg.solve(AAt, A @ rhs_n)
+            got = aug.project_nullspace(SleqpVec.from_raw(rhs_n)).to_raw()
+            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+                errs.append(f"step {step}: projection rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
+    if fv.info("dataflow_fallbacks") or fa.info("dataflow_fallbacks"):
+        errs.append("a dataflow launch timed out")
+    return tag, errs
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -233,7 +331,10 @@ def main():
             continue
         rng = np.random.default_rng([seed, idx])
         try:
-            tag, res = one_case(fact, rng, idx)
+            if os.environ.get("FUZZ_MODE") == "sequence":
+                tag, res = sequence_case(rng, idx)
+            else:
+                tag, res = one_case(fact, rng, idx)
         except Exception as e:  # noqa: BLE001
             tag, res = f"case {idx} ({LAST_TAG[0]})", [f"exception {type(e).__name__}: {e}", traceback.format_exc(limit=3)]
             fact = HipFact()
@@ -245,7 +346,7 @@ def main():
             print(tag, flush=True)
             for r in res:
                 print("   ", r, flush=True)
-    print(f"{cases} cases (seed {seed}): {failed} failed, {skipped} skipped", flush=True)
+    print(f"{cases} cases (seed {seed}): {failed} failed, {skipped} skipped" + (f", {STEPS[0]} working sets checked" if STEPS[0] else ""), flush=True)
     sys.exit(1 if failed else 0)
 
 
