@@ -106,7 +106,7 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
         res = scaled_residual(K, z, b)
         rel = float(np.linalg.norm(z - want) / max(np.linalg.norm(want), 1e-300))
         # (the forward error is the condition's doing: SuperLU's own answer is no better)
-        if not (res <= 1e-11) or not (rel <= max(1e-6, 1e-13 * cond_proxy)):
+        if not (res <= 1e-11) or not (rel <= max(1e-5, 1e-13 * cond_proxy)):
             errs.append(f"solve {rep}: scaled residual {res:.2e}, rel diff vs SuperLU {rel:.2e}")
     for rep in range(int(os.environ.get("FUZZ_EXTRA_SOLVES", "0"))):
         b = rng.standard_normal(N)
@@ -209,6 +209,23 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
         except Exception:  # noqa: BLE001
             pass
         fact.set_option("cg_device_loop", 1)
+        if "gltr" in krylov_checks:
+            # the matrix-free product of the problem (callback) instead of the Hessian in HBM, and small iteration caps
+            s_mf, d_mf, i_mf = fact.tr_solve(lambda v: Hs @ v, g, radius, method=1, stat_tol=tol, max_iter=300)
+            sa, da, ia = out["gltr_host"]
+            if abs(i_mf - ia) > 1 or np.linalg.norm(s_mf - sa) > 1e-6 * max(np.linalg.norm(sa), 1e-300):
+                errs.append(f"GLTR matrix-free vs explicit Hessian: its {i_mf}/{ia}, rel diff {np.linalg.norm(s_mf - sa) / max(np.linalg.norm(sa), 1e-300):.2e}")
+            for cap in (1, 2, 9):
+                if n - W < 2 * cap + 2:
+                    continue  # (the Krylov space would be exhausted: what follows is rounding noise on either side)
+                res = {}
+                for dev in (1, 0):
+                    fact.set_option("lz_device_loop", dev)
+                    res[dev] = fact.tr_solve(H, g, radius, method=1, stat_tol=1e-30, max_iter=cap)
+                fact.set_option("lz_device_loop", 1)
+                (s1, d1, i1), (s0, d0, i0) = res[1], res[0]
+                if i1 != i0 or np.linalg.norm(s1 - s0) > 1e-8 * max(np.linalg.norm(s0), 1e-300) or abs(d1 - d0) > 1e-8 * max(1.0, abs(d0)):
+                    errs.append(f"GLTR cap {cap}: device phase vs host loop its {i1}/{i0}, rel diff {np.linalg.norm(s1 - s0) / max(np.linalg.norm(s0), 1e-300):.2e}")
         (sa, da, ia), (sb, db, ib) = out["gltr_dev"], out["gltr_host"]
         # (one iteration more or less where the convergence test is met to rounding is not a difference)
         if abs(ia - ib) > 1 or np.linalg.norm(sa - sb) > 1e-6 * max(np.linalg.norm(sb), 1e-300) or abs(da - db) > 1e-6 * max(1.0, abs(db)):
