@@ -48,12 +48,13 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
     if tol is None:
         tol = float(os.environ.get("FUZZ_TOL", "1e-4"))
     kind = rng.choice(["banded", "uniform"])
-    n = int(rng.choice([40, 150, 600, 1500, 4000, 12000]))
+    sizes = [int(v) for v in os.environ.get("FUZZ_SIZES", "40,150,600,1500,4000,12000").split(",")]
+    n = int(rng.choice(sizes))
     m = max(1, int(n * rng.choice([0.2, 0.5, 0.8])))
     if kind == "banded":
         J = synth.banded_jacobian(n, m, int(min(rng.integers(3, 14), n)), int(min(rng.integers(20, 200), n)), int(rng.integers(1 << 30)))
     else:
-        if n > 4000:
+        if n > 4000 and not os.environ.get("FUZZ_SIZES"):
             n, m = 1500, 700
         J = synth.uniform_jacobian(n, m, int(min(rng.integers(2, 6), n)), int(rng.integers(1 << 30)))
     extra = rng.choice(["none", "none", "dense_cols", "dense_rows", "both", "many_cols"])
