@@ -72,8 +72,15 @@ def run():
     for l in range(int(f.info("factor_top_level")), P.nlevels):
         m_ = lev[front] == l
         pv, pn, sc = m_ & (role == 0), m_ & (role == 1), m_ & (role == 2)
-        def mx(a): return a.max() if a.size else float("nan")
-        def mn(a): return a.min() if a.size else float("nan")
+        # (a stamp that was never taken - a workgroup beyond the trace slots, a branch without that mark - is 0 in the raw
+        # record, i.e. far below zero after the shift to the launch's first stamp: left out, not averaged in)
+        def mx(a):
+            a = a[a > -1e6]
+            return a.max() if a.size else float("nan")
+
+        def mn(a):
+            a = a[a > -1e6]
+            return a.min() if a.size else float("nan")
         w_ = tt[pv, 1]; w_ = w_[w_ > 0]
         print(f"  level {l:2d}  fronts {int(pv.sum()):4d}  panel wgs {int(pn.sum()):4d}  schur wgs {int(sc.sum()):5d}  pivots start {mn(tt[pv, 0]):7.1f}  waited {mn(w_) if w_.size else 0:7.1f} .. {mx(w_) if w_.size else 0:7.1f}"
               f"  pivots done {mx(tt[pv, 2]):7.1f}  panels published {mx(tt[pn, 3]):7.1f}  schur published {mx(tt[sc, 3]):7.1f}")
