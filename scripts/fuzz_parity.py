@@ -338,6 +338,49 @@ def sequence_case(rng, idx):
     return tag, errs
 
 
+def spmv_case(fact, rng, idx):
+    """The sparse products around the EQP step (J x, J^T y, the symmetric Hessian product from its lower triangle) on
+    random shapes - empty rows and columns, single entries, rows of very different lengths - against scipy, and after
+    update_values."""
+    r = int(rng.choice([1, 2, 7, 64, 500, 3000]))
+    c = int(rng.choice([1, 3, 50, 700, 4000]))
+    dens = float(rng.choice([0.0, 0.002, 0.02, 0.3]))
+    M = sp.random(r, c, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+    if rng.random() < 0.3 and r > 2:
+        M = sp.csc_matrix(M + sp.csc_matrix((np.ones(c), (np.full(c, int(rng.integers(r))), np.arange(c))), shape=(r, c)))  # a dense row
+    M.sort_indices()
+    tag = f"spmv {idx}: {r} x {c}, nnz {M.nnz}"
+    LAST_TAG[0] = tag
+    errs = []
+    S = SpMat(fact, SleqpMat.from_scipy(M))
+    for rep in range(2):
+        x, y = rng.standard_normal(c), rng.standard_normal(r)
+        scale = max(abs(M).sum(axis=1).max() if M.nnz else 0.0, 1.0)
+        got = S.mult_vec(x)
+        if np.abs(got - M @ x).max() > 1e-13 * scale * max(np.abs(x).max(), 1.0):
+            errs.append(f"M x: max diff {np.abs(got - M @ x).max():.2e}")
+        got = S.mult_vec_trans(y).to_raw()
+        scale_t = max(abs(M).sum(axis=0).max() if M.nnz else 0.0, 1.0)
+        if np.abs(got - M.T @ y).max() > 1e-13 * scale_t * max(np.abs(y).max(), 1.0):
+            errs.append(f"M^T y: max diff {np.abs(got - M.T @ y).max():.2e}")
+        M = sp.csc_matrix((M.data * (1.0 + rng.standard_normal(M.nnz)), M.indices, M.indptr), shape=M.shape)
+        S.update_values(M.data)
+    S.free()
+    k = min(r, c)
+    B = sp.random(k, k, density=min(1.0, dens * 3 + 1.0 / k), random_state=int(rng.integers(1 << 30)))
+    HL = sp.tril(B + B.T, format="csc")
+    HL.sort_indices()
+    Hs = (HL + HL.T - sp.diags(HL.diagonal())).tocsr()
+    S = SpMat(fact, SleqpMat.from_scipy(HL))
+    x = rng.standard_normal(k)
+    got = S.mult_vec_sym(x)
+    scale = max(abs(Hs).sum(axis=1).max() if Hs.nnz else 0.0, 1.0)
+    if np.abs(got - Hs @ x).max() > 1e-13 * scale * max(np.abs(x).max(), 1.0):
+        errs.append(f"symmetric product: max diff {np.abs(got - Hs @ x).max():.2e}")
+    S.free()
+    return tag, errs
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -351,6 +394,8 @@ def main():
         try:
             if os.environ.get("FUZZ_MODE") == "sequence":
                 tag, res = sequence_case(rng, idx)
+            elif os.environ.get("FUZZ_MODE") == "spmv":
+                tag, res = spmv_case(fact, rng, idx)
             else:
                 tag, res = one_case(fact, rng, idx)
         except Exception as e:  # noqa: BLE001
