@@ -381,6 +381,49 @@ def spmv_case(fact, rng, idx):
     return tag, errs
 
 
+def generic_case(fact, rng, idx):
+    """Symmetric positive definite matrices without the saddle structure (the reduced / PSD backend of
+    fact_cholmod.c's role): lower CSC through hipfact_set_matrix, dense and sparse right-hand sides, solution ranges."""
+    N = int(rng.choice([1, 2, 9, 130, 900, 5000]))
+    kind = rng.choice(["random", "banded"])
+    if kind == "random":
+        B = sp.random(N, N, density=min(1.0, float(rng.choice([1.0, 3.0, 8.0])) / N), random_state=int(rng.integers(1 << 30)))
+        S = (B @ B.T + float(rng.choice([0.1, 1.0, 10.0])) * sp.eye(N)).tocsc()
+    else:
+        w = int(min(N - 1, rng.integers(1, 12))) if N > 1 else 0
+        diags = [np.full(N, 4.0 * (w + 1))] + [rng.standard_normal(N - k) for k in range(1, w + 1)]
+        L = sp.diags(diags, [-k for k in range(0, w + 1)], format="csc")
+        S = (L + L.T - sp.diags(L.diagonal())).tocsc()
+    SL = sp.tril(S, format="csc")
+    SL.sort_indices()
+    tag = f"generic {idx}: N={N} {kind} nnz {SL.nnz}"
+    LAST_TAG[0] = tag
+    errs = []
+    fact.set_matrix(SleqpMat(N, N, SL.indptr.astype(np.int32), SL.indices.astype(np.int32), SL.data))
+    lu = spla.splu(S.tocsc())
+    b = rng.standard_normal(N)
+    fact.solve(b)
+    z = fact.solution_raw(0, N)
+    if scaled_residual(S, z, b) > 1e-12 or np.linalg.norm(z - lu.solve(b)) > 1e-8 * max(np.linalg.norm(z), 1e-300):
+        errs.append(f"dense rhs: scaled residual {scaled_residual(S, z, b):.2e}")
+    # sparse right-hand side (a few entries, possibly none), ranges of the solution
+    k = int(rng.integers(0, min(N, 6) + 1))
+    ind = np.sort(rng.choice(N, k, replace=False)).astype(np.int32)
+    val = rng.standard_normal(k)
+    bs = np.zeros(N)
+    bs[ind] = val
+    fact.solve(SleqpVec(N, ind, val))
+    lo = int(rng.integers(0, N + 1))
+    hi = int(rng.integers(lo, N + 1))
+    part = fact.solution_raw(lo, hi)
+    full = fact.solution_raw(0, N)
+    if not np.array_equal(part, full[lo:hi]):
+        errs.append("solution range differs from the slice of the whole solution")
+    if scaled_residual(S, full, bs) > 1e-12:
+        errs.append(f"sparse rhs: scaled residual {scaled_residual(S, full, bs):.2e}")
+    return tag, errs
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -396,6 +439,8 @@ def main():
                 tag, res = sequence_case(rng, idx)
             elif os.environ.get("FUZZ_MODE") == "spmv":
                 tag, res = spmv_case(fact, rng, idx)
+            elif os.environ.get("FUZZ_MODE") == "generic":
+                tag, res = generic_case(fact, rng, idx)
             else:
                 tag, res = one_case(fact, rng, idx)
         except Exception as e:  # noqa: BLE001
