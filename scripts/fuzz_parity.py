@@ -424,6 +424,62 @@ def generic_case(fact, rng, idx):
     return tag, errs
 
 
+def alternate_case(rng, idx):
+    """ONE handle, several patterns visited in random order with new values every time (plan cache: parked states with
+    their graphs, top blocks and refinement state swapped in and out, evictions beyond plan_cache), several solves each."""
+    f = HipFact()
+    npat = int(rng.integers(3, 8))
+    f.set_option("plan_cache", int(rng.choice([1, 2, 4])))
+    pats = []
+    from scipy.sparse.csgraph import structural_rank
+
+    tries = 0
+    while len(pats) < npat and tries < 40:
+        tries += 1
+        n = int(rng.choice([50, 400, 2000, 6000]))
+        m = max(2, int(n * rng.choice([0.3, 0.6])))
+        J = synth.banded_jacobian(n, m, int(min(rng.integers(3, 10), n)), int(min(rng.integers(20, 120), n)), int(rng.integers(1 << 30))) \
+            if rng.random() < 0.6 else synth.uniform_jacobian(n, m, int(min(rng.integers(2, 5), n)), int(rng.integers(1 << 30)))
+        vi, ci, _ = synth.working_set_all_rows(n, m, float(rng.choice([0.0, 0.05])), int(rng.integers(1 << 30)))
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(sp.csc_matrix(J), vi, ci)
+        K0 = synth.kkt_full_matrix(N, kc, kr, kd).tocsc()
+        if structural_rank(K0) < N or (N <= 500 and np.linalg.matrix_rank(K0.toarray()) < N):
+            continue
+        try:
+            dg = np.abs(spla.splu(K0).U.diagonal())
+        except RuntimeError:
+            continue
+        if not (dg.max() / max(dg.min(), 1e-300) <= 1e8):
+            continue
+        pats.append((n, N, kc, kr, np.array(kd, copy=True)))
+    npat = len(pats)
+    tag = f"alternate {idx}: {npat} patterns"
+    if npat == 0:
+        return tag, "skipped"
+    LAST_TAG[0] = tag
+    errs = []
+    for visit in range(int(rng.integers(8, 20))):
+        n, N, kc, kr, kd = pats[int(rng.integers(npat))]
+        vals = np.array(kd, copy=True)
+        off = np.ones(len(vals), dtype=bool)
+        off[np.asarray(kc[:n])] = False
+        unit = (vals == 1.0)
+        chg = off & ~unit
+        vals[chg] *= 1.0 + 0.1 * rng.standard_normal(int(chg.sum()))
+        K = synth.kkt_full_matrix(N, kc, kr, vals).tocsc()
+        f.set_matrix(SleqpMat(N, N, kc, kr, vals))
+        for rep in range(int(rng.integers(1, 5))):
+            b = rng.standard_normal(N)
+            f.solve(b)
+            z = f.solution_raw(0, N)
+            res = scaled_residual(K, z, b)
+            if not (res <= 1e-10):
+                errs.append(f"visit {visit} (N={N}) solve {rep}: scaled residual {res:.2e}")
+    if f.info("dataflow_fallbacks"):
+        errs.append("a dataflow launch timed out")
+    return tag, errs
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -441,6 +497,8 @@ def main():
                 tag, res = spmv_case(fact, rng, idx)
             elif os.environ.get("FUZZ_MODE") == "generic":
                 tag, res = generic_case(fact, rng, idx)
+            elif os.environ.get("FUZZ_MODE") == "alternate":
+                tag, res = alternate_case(rng, idx)
             else:
                 tag, res = one_case(fact, rng, idx)
         except Exception as e:  # noqa: BLE001
