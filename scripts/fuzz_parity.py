@@ -333,6 +333,21 @@ def sequence_case(rng, idx):
             got = aug.project_nullspace(SleqpVec.from_raw(rhs_n)).to_raw()
             if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
                 errs.append(f"step {step}: projection rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
+        # the trust-region loops on the superset plan of this run (H = c I inside a large region: the step is -P g / c)
+        if W < n:
+            cH = 2.5
+            Hc = SpMat(fa, SleqpMat.from_scipy(sp.csc_matrix(sp.identity(n, format="csc") * cH)))
+            gk = rng.standard_normal(n)
+            pg = aug.project_nullspace(SleqpVec.from_raw(gk)).to_raw()
+            for method, opt in ((1, "lz_device_loop"), (0, "cg_device_loop")):
+                for dev in (1, 0):
+                    fa.set_option(opt, dev)
+                    st, _, its = fa.tr_solve(Hc, gk, 1e8, method=method, stat_tol=1e-5, max_iter=50)
+                    if np.linalg.norm(st + pg / cH) > 1e-6 * max(np.linalg.norm(pg / cH), 1e-300) or its > 4:
+                        errs.append(f"step {step}: {'GLTR' if method else 'CG'} (device loop {dev}) rel diff "
+                                    f"{np.linalg.norm(st + pg / cH) / max(np.linalg.norm(pg / cH), 1e-300):.2e} in {its} iterations")
+                fa.set_option(opt, 1)
+            Hc.free()
     if fv.info("dataflow_fallbacks") or fa.info("dataflow_fallbacks"):
         errs.append("a dataflow launch timed out")
     return tag, errs

@@ -66,3 +66,33 @@ def test_short_random_sweep():
     assert ran >= 25
     assert failures == []
     assert fact.info("dataflow_fallbacks") == 0
+
+
+@pytest.mark.gpu
+def test_short_sweeps_of_the_other_modes():
+    """Working-set sequences through both boundaries (AugJac solves against dense formulas, the trust-region loops on the
+    superset plan), one handle across several patterns (plan cache), positive definite matrices without the saddle
+    structure (sparse right-hand sides, solution ranges), the sparse products on random shapes."""
+    from sleqp_amd.fact import HipFact
+
+    fz = _fuzz()
+    failures = []
+    for idx in range(10):
+        tag, res = fz.sequence_case(np.random.default_rng([12, idx]), idx)
+        if res and not isinstance(res, str):
+            failures.append((tag, res))
+    assert fz.STEPS[0] >= 30
+    for idx in range(6):
+        tag, res = fz.alternate_case(np.random.default_rng([13, idx]), idx)
+        if res and not isinstance(res, str):
+            failures.append((tag, res))
+    fact = HipFact()
+    for idx in range(40):
+        tag, res = fz.generic_case(fact, np.random.default_rng([14, idx]), idx)
+        if res:
+            failures.append((tag, res))
+    for idx in range(80):
+        tag, res = fz.spmv_case(fact, np.random.default_rng([15, idx]), idx)
+        if res:
+            failures.append((tag, res))
+    assert failures == []
