@@ -299,6 +299,8 @@ def sequence_case(rng, idx):
         if not np.isfinite(dg.max() / max(dg.min(), 1e-300)) or dg.max() / max(dg.min(), 1e-300) > 1e9:
             continue
         W = N - n
+        # (the dense formulas below go through A A^T themselves: their own error grows with the condition)
+        thr = max(1e-7, 1e-14 * dg.max() / max(dg.min(), 1e-300))
         STEPS[0] += 1
         b = rng.standard_normal(N)
         for name, f in (("vtable", fv), ("augjac", fa)):
@@ -322,16 +324,16 @@ def sequence_case(rng, idx):
             rhs_w = rng.standard_normal(W)
             want = A.T @ np.linalg.solve(AAt, rhs_w)
             got = aug.solve_min_norm(SleqpVec.from_raw(rhs_w)).to_raw()
-            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+            if np.linalg.norm(got - want) > thr * max(np.linalg.norm(want), 1e-300):
                 errs.append(f"step {step}: min-norm solve rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
             rhs_n = rng.standard_normal(n)
             want = np.linalg.solve(AAt, A @ rhs_n)
             got = aug.solve_lsq(SleqpVec.from_raw(rhs_n)).to_raw()
-            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+            if np.linalg.norm(got - want) > thr * max(np.linalg.norm(want), 1e-300):
                 errs.append(f"step {step}: least-squares solve rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
             want = rhs_n - A.T @ np.linalg.solve(AAt, A @ rhs_n)
             got = aug.project_nullspace(SleqpVec.from_raw(rhs_n)).to_raw()
-            if np.linalg.norm(got - want) > 1e-7 * max(np.linalg.norm(want), 1e-300):
+            if np.linalg.norm(got - want) > thr * max(np.linalg.norm(want), 1e-300):
                 errs.append(f"step {step}: projection rel diff {np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300):.2e}")
         # the trust-region loops on the superset plan of this run (H = c I inside a large region: the step is -P g / c)
         if W < n:
