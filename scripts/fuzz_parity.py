@@ -238,6 +238,11 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
         if "cg" in krylov_checks and q(out["gltr_dev"][0]) > q(out["cg_dev"][0]) + 1e-6 * abs(q(out["cg_dev"][0])):
             errs.append(f"GLTR model value {q(out['gltr_dev'][0]):.8e} worse than CG {q(out['cg_dev'][0]):.8e}")
         H.free()
+    if os.environ.get("FUZZ_VERBOSE"):
+        try:
+            print(f"   dense fallbacks {int(fact.info('dense_fallbacks'))}, probes {int(fact.info('dense_probes'))}", file=sys.stderr, flush=True)
+        except Exception:  # noqa: BLE001
+            pass
     return tag, errs
 
 
