@@ -118,6 +118,8 @@ struct SolveItem {
   // adds them in slice order.  One item per front otherwise (a0 = 0, a1 = r - w, nsl = 1).
   int a0, a1, sl, nsl;
   long long poff;            // the front's (nsl - 1) x w partial sums in the partial-sum arena
+  int plevel, pad_;          // level of the parent front (-1: a root): a front whose parent lies in the top block of
+                             // the solve sends its whole update vector into that block (TopBlockIn::ltop)
 };
 // Rows of A / columns of K longer than this are not walked by the few lanes of the streaming kernels (16 per row, 8 per
 // column: a dense constraint row or a dense Jacobian column would be tens of thousands of dependent iterations of one
@@ -182,6 +184,7 @@ struct TopBlockIn {
   // the rows of y_T it needs are posted - by ONE item, while another may not have gathered yet: the backward items
   // put their update slots back to the sentinel only once all ntf items have read them.
   unsigned int* __restrict__ gathered2;
+  int ltop;  // first level of T (only the children of T's fronts feed the block: they are the ones that wait)
 };
 constexpr int SOLVE_PREFETCH = 32;  // panel entries per thread requested before the dependency wait
 
