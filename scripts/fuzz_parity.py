@@ -251,7 +251,7 @@ def sequence_case(rng, idx):
     vtable (K assembled on the host, row dictionary and superset plan behind hipfact_set_matrix) and the AugJac mirror
     (device assembly) - with min-norm, least-squares and projection solves against dense references."""
     kind = rng.choice(["banded", "uniform"])
-    n = int(rng.choice([60, 300, 1200, 3000]))
+    n = int(rng.choice([int(v) for v in os.environ.get("FUZZ_SEQ_SIZES", "60,300,1200,3000").split(",")]))
     m = max(2, int(n * rng.choice([0.3, 0.6])))
     if kind == "banded":
         J = synth.banded_jacobian(n, m, int(min(rng.integers(3, 10), n)), int(min(rng.integers(20, 120), n)), int(rng.integers(1 << 30)))
