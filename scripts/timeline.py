@@ -41,6 +41,8 @@ def run():
     J, N, cp, ri, vx, b = make_problem(sys.argv[2] if len(sys.argv) > 2 else "banded_n1e5_m5e4", 0)
     f = HipFact(device=0)
     f.set_option("use_graph", 0)
+    for kv in os.environ.get("HIPFACT_TIMELINE_OPTS", "").split():
+        f.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     for _ in range(3):
         f.set_matrix(SleqpMat(N, N, cp, ri, vx))
     lib = _lib.load()
@@ -71,7 +73,7 @@ def run():
     print("# per level of the dataflow launch (us): fronts, pivots waited (first..last), pivots done (last), panels published (last), Schur published (last)")
     for l in range(int(f.info("factor_top_level")), P.nlevels):
         m_ = lev[front] == l
-        pv, pn, sc = m_ & (role == 0), m_ & (role == 1), m_ & (role == 2)
+        pv, pn, sc = m_ & (role == 0), m_ & (role == 1), m_ & ((role == 2) | (role == 4))
         # (a stamp that was never taken - a workgroup beyond the trace slots, a branch without that mark - is 0 in the raw
         # record, i.e. far below zero after the shift to the launch's first stamp: left out, not averaged in)
         def mx(a):
@@ -87,14 +89,14 @@ def run():
     print("# per level and role: workgroups, mean us resident before their wait ended, mean us of work behind the wait, mean us to publish; "
           "(panel / Schur: the wait is for the own front's pivot / panel workgroups)")
     for l in range(int(f.info("factor_top_level")), P.nlevels):
-        m_ = (lev[front] == l) & (role < 3)
+        m_ = (lev[front] == l) & (role != 3)
         parts = []
-        for rr, nm in ((0, "pivot"), (1, "panel"), (2, "schur")):
+        for rr, nm in ((0, "pivot"), (1, "panel"), (2, "schur"), (4, "fused")):
             k_ = m_ & (role == rr) & (tt[:, 1] > 0) & (tt[:, 2] > 0)
             if k_.any():
                 parts.append(f"{nm} {int(k_.sum()):4d}: wait {np.mean(tt[k_, 1] - tt[k_, 0]):6.1f}  work {np.mean(tt[k_, 2] - tt[k_, 1]):5.1f}  publish {np.mean(tt[k_, 3] - tt[k_, 2]):4.1f}")
         print(f"  level {l:2d}  " + "   ".join(parts))
-    names = ["pivot", "panel", "schur", "spanl"]
+    names = ["pivot", "panel", "schur", "spanl", "fused"]
     sp = role == 3
     if sp.any():
         # solve-panel items (role 3): stamped at start only (slot 0); their end is not on the record, so the window
@@ -108,11 +110,12 @@ def run():
     print("# workgroup role front | us since the first workgroup started: start, before its (last) wait, after it, "
           "work done, published")
     crit = [i for i in range(n) if role[i] != 3]
-    for i in crit[-60:]:
+    for i in crit[-int(os.environ.get("HIPFACT_TIMELINE_TAIL", "60")):]:
         extra = ""
-        print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {tt[i, 5]:8.2f}  waited {tt[i, 1]:8.2f}"
+        pre = tt[i, 5] if t[i, 5] > 0 else float("nan")  # (a stamp that was never taken is 0 in the raw record)
+        print(f"{i:5d} {names[role[i]]:5s} f{front[i]:4d}  start {tt[i, 0]:8.2f}  prewait {pre:8.2f}  waited {tt[i, 1]:8.2f}"
               f"  done {tt[i, 2]:8.2f}  published {tt[i, 3]:8.2f}{extra}")
-        if role[i] == 1 and i >= crit[-30]:
+        if role[i] in (1, 4) and i >= crit[-30]:
             base = t[:, 0][t[:, 0] > 0].min()
             print("        panel, per block row: polled " + " ".join(f"{(x - base) / 100.0:.2f}" for x in piv[i][8:16] if x > 0)
                   + " | barrier " + " ".join(f"{(x - base) / 100.0:.2f}" for x in piv[i][0:8] if x > 0)

@@ -59,7 +59,7 @@ struct PairDesc {
 // one workgroup of the single-launch top-of-tree factorisation kernel
 struct TopFItem {
   FrontItem it;
-  int role;   // 0 pivot, 1 panel, 2 Schur
+  int role;   // 0 pivot, 1 panel, 2 Schur, 3 solve panels, 4 panel rows + Schur tile in one (kernels_front_fused.inc)
   int front;  // index of the front's counters
   int part2;  // Schur: the second team's tile
   int nwait;  // number of children
@@ -167,6 +167,7 @@ struct TopChunk {
 constexpr int TOP_CB = 8;
 // LDS doubles of a k_solve_tree workgroup; a top-block item needs nT + 1024 + (nT + 1 + sources + 1) / 2 of them
 constexpr int TOP_LDS = 7 * 1024 + 512;
+constexpr int TREE_LDS = 2 * 1024 + 8;  // k_solve_tree without a top block (dynamic LDS, doubles)
 struct TopBlockIn {
   int nT, ntf, ntb;
   const TopBlockItem* __restrict__ items;  // ntf forward items, then ntb backward items
