@@ -453,15 +453,17 @@ def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     return out
 
 
-def device_unit(J, local_rank, reps=12, solves=20):
-    """Device-resident numeric refactorisation + solve of K(J) (values and right-hand side in HBM), plan statistics."""
+def device_unit(J, local_rank, reps=12, solves=20, ws=None, vtable=False):
+    """Device-resident numeric refactorisation + solve of K(J) (values and right-hand side in HBM), plan statistics.
+    ws: (var_index, cons_index) of the working set (default: every constraint row, no active bound);
+    vtable: also the unit through the host boundary (set_matrix(K) + solve(rhs) + solution(0, n), PCIe both ways)."""
     import torch
 
     from sleqp_amd import synth
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
-    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, *(ws or ()))
     f = HipFact(device=local_rank)
     t0 = time.perf_counter()
     f.set_matrix(SleqpMat(N, N, cp, ri, vx))
@@ -499,6 +501,20 @@ def device_unit(J, local_rank, reps=12, solves=20):
     out = {"factor_plus_solve_ms": t_unit * 1e3, "factor_ms": t_fac * 1e3, "solve_ms": t_sol * 1e3, "levels": int(f.info("nlevels")),
            "fronts": int(f.info("nsuper")), "nnzL": f.info("nnzL_true"), "flops": f.info("flops"), "late_columns": int(f.info("late_columns")),
            "late_rows": int(f.info("late_rows")), "analysis_s": f.info("analysis_s"), "cold_set_matrix_s": cold, "scaled_residual": resid}
+    if vtable:
+        n = J.shape[1]
+        Km = SleqpMat(N, N, cp, ri, vx)
+        for _ in range(2):
+            f.set_matrix(Km)
+            f.solve(bb)
+            f.solution_raw(0, n)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f.set_matrix(Km)
+            f.solve(bb)
+            f.solution_raw(0, n)
+        out["vtable_unit_ms"] = (time.perf_counter() - t0) / reps * 1e3
+        out["analyses"] = int(f.info("analyses"))
     f.free()
     return out
 
@@ -518,6 +534,15 @@ def structural_robustness_bench(J4, local_rank):
                          ("config4_plus_100_dense_columns", synth.with_dense_columns(J4, 100, 3)[0])):
             r = device_unit(Jx, local_rank)
             r["factor_plus_solve_vs_base"] = r["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
+            out[name] = r
+        # active bounds (working_set.c:139: the unit rows of active bounds come first in every working set; SURVEY 8(d)
+        # names the variant): eliminated in front of the analysis on every path, the tree stays that of the rows
+        n4, m4 = J4.shape[1], J4.shape[0]
+        for name, frac in (("config4_plus_10pct_bounds", 0.1), ("config4_plus_30pct_bounds", 0.3)):
+            vi, ci, _ = synth.working_set_all_rows(n4, m4, frac, 0)
+            r = device_unit(J4, local_rank, ws=(vi, ci), vtable=True)
+            r["factor_plus_solve_vs_base"] = r["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
+            r["active_bounds"] = int((vi >= 0).sum())
             out[name] = r
         J2 = synth.banded_jacobian(20000, 10000, 20, 200, 0)
         b2 = device_unit(J2, local_rank)

@@ -332,7 +332,7 @@ sleqp_fact_hipfact_psd_create(SleqpFact** star, SleqpSettings* settings)
 
     if (status == HIPFACT_OK)
     {
-      status = hipfact_set_option(data->handle, "superset_vtable", 0.);
+      status = hipfact_set_option(data->handle, "exact_pattern", 1.);
     }
 
     if (status != HIPFACT_OK)

@@ -1309,4 +1309,91 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
   return true;
 }
 
+
+bool build_plan_bounds(int N, const int* Kp, const int* Ki, const double* Kx, const PlanParams& prm, Plan& P) {
+  auto plain = [&] {
+    const bool ok = build_plan(N, Kp, Ki, Kx, prm, P);
+    P.N_ext = N;
+    return ok;
+  };
+  if (N <= 0 || !Kp || !Ki || prm.force_generic) return plain();
+  int n = N;
+  while (n > 0 && Kp[n] == Kp[n - 1]) --n;
+  const int W = N - n;
+  if (n == 0 || W == 0) return plain();
+  // shape of the leading columns: unit diagonal first, everything else in the (2,1) block, ascending (anything else is
+  // build_plan's to classify or refuse)
+  std::vector<int> cnt((size_t)W, 0), one((size_t)W, -1);
+  for (int j = 0; j < n; ++j) {
+    const int a = Kp[j], b = Kp[j + 1];
+    if (a >= b || Ki[a] != j || (Kx && Kx[a] != 1.0)) return plain();
+    for (int e = a + 1; e < b; ++e) {
+      if (Ki[e] < n || Ki[e] >= N || (e > a + 1 && Ki[e] <= Ki[e - 1])) return plain();
+      ++cnt[(size_t)(Ki[e] - n)];
+      one[(size_t)(Ki[e] - n)] = e;
+    }
+  }
+  // unit rows: one entry (of value one).  Two of them on one variable are a rank-deficient K: not touched here.
+  std::vector<int> fixed_by((size_t)n, -1);  // variable -> its unit row
+  std::vector<char> is_bound((size_t)W, 0);
+  int nb = 0;
+  for (int r = 0; r < W; ++r)
+    if (cnt[(size_t)r] == 1 && (!Kx || Kx[one[(size_t)r]] == 1.0)) {
+      const int j = (int)(std::upper_bound(Kp, Kp + n + 1, one[(size_t)r]) - Kp) - 1;
+      if (fixed_by[(size_t)j] >= 0) return plain();
+      fixed_by[(size_t)j] = r;
+      is_bound[(size_t)r] = 1;
+      ++nb;
+    }
+  if (nb == 0) return plain();
+  // K': the other rows renumbered, the fixed variables' columns cut down to their diagonal
+  std::vector<int> newrow((size_t)W, -1), row_ext;
+  for (int r = 0; r < W; ++r)
+    if (!is_bound[(size_t)r]) {
+      newrow[(size_t)r] = (int)row_ext.size();
+      row_ext.push_back(r);
+    }
+  const int W2 = (int)row_ext.size(), N2 = n + W2;
+  std::vector<int> kp2((size_t)N2 + 1, 0), ki2, ent, bnd_row, bnd_col, cut_ptr{0}, cut_row, cut_ent;
+  std::vector<double> kx2;
+  ki2.reserve((size_t)Kp[N]);
+  ent.reserve((size_t)Kp[N]);
+  for (int j = 0; j < n; ++j) {
+    ki2.push_back(j);
+    ent.push_back(Kp[j]);
+    if (fixed_by[(size_t)j] >= 0) {
+      bnd_row.push_back(fixed_by[(size_t)j]);
+      bnd_col.push_back(j);
+      for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e)
+        if (!is_bound[(size_t)(Ki[e] - n)]) {
+          cut_row.push_back(newrow[(size_t)(Ki[e] - n)]);
+          cut_ent.push_back(e);
+        }
+      cut_ptr.push_back((int)cut_row.size());
+    } else {
+      for (int e = Kp[j] + 1; e < Kp[j + 1]; ++e) {
+        ki2.push_back(n + newrow[(size_t)(Ki[e] - n)]);  // (rows of free columns are never bound rows: those have one entry)
+        ent.push_back(e);
+      }
+    }
+    kp2[(size_t)j + 1] = (int)ki2.size();
+  }
+  for (int j = n; j < N2; ++j) kp2[(size_t)j + 1] = kp2[(size_t)n];
+  if (Kx) {
+    kx2.resize(ent.size());
+    for (size_t e = 0; e < ent.size(); ++e) kx2[e] = Kx[ent[e]];
+  }
+  const bool ok = build_plan(N2, kp2.data(), ki2.data(), Kx ? kx2.data() : nullptr, prm, P);
+  P.N_ext = N;
+  P.n_bounds = nb;
+  P.bnd_row = std::move(bnd_row);
+  P.bnd_col = std::move(bnd_col);
+  P.row_ext = std::move(row_ext);
+  P.ent_ext = std::move(ent);
+  P.cut_ptr = std::move(cut_ptr);
+  P.cut_row = std::move(cut_row);
+  P.cut_ent = std::move(cut_ent);
+  return ok;
+}
+
 }  // namespace hipfact

@@ -21,7 +21,7 @@ int hipfact_plan_create(int N, const int* colptr, const int* rowidx, const doubl
   hipfact::PlanParams prm;
   *out = p;
   try {
-    if (!hipfact::build_plan(N, colptr, rowidx, vals, prm, p->plan)) return HIPFACT_EINVAL;
+    if (!hipfact::build_plan_bounds(N, colptr, rowidx, vals, prm, p->plan)) return HIPFACT_EINVAL;
   } catch (const std::bad_alloc&) {
     p->plan.error = "out of memory";
     return HIPFACT_ENOMEM;
@@ -55,6 +55,7 @@ int hipfact_plan_array(const hipfact_plan* plan, const char* name, const void** 
   ARR(sn_c0) ARR(sn_r) ARR(sn_rowptr) ARR(sn_rows) ARR(sn_parent) ARR(sn_level) ARR(sn_Loff) ARR(sn_Uoff)
   ARR(sn_uoff) ARR(child_ptr) ARR(child_idx) ARR(rel_ptr) ARR(rel) ARR(level_ptr) ARR(level_sn) ARR(Ar_ptr)
   ARR(Ar_col) ARR(Ar_src) ARR(Kc_y) ARR(dense_cols) ARR(late_cols)
+  ARR(bnd_row) ARR(bnd_col) ARR(row_ext) ARR(ent_ext) ARR(cut_ptr) ARR(cut_row) ARR(cut_ent)
 #undef ARR
   return HIPFACT_EINVAL;
 }
@@ -69,7 +70,7 @@ int hipfact_plan_scalar(const hipfact_plan* plan, const char* name, double* valu
   }
   SC(N) SC(n) SC(m) SC(my) SC(n_late) SC(n_late_rows) SC(saddle) SC(nnzK) SC(nsuper) SC(nlevels) SC(L_size) SC(U_size) SC(u_size) SC(nnzL)
   SC(nnzL_true) SC(flops) SC(flops_dense) SC(nprod) SC(max_r) SC(max_w) SC(max_u) SC(t_order) SC(t_symbolic)
-  SC(t_total)
+  SC(t_total) SC(N_ext) SC(n_bounds)
 #undef SC
   return HIPFACT_EINVAL;
 }

@@ -17,10 +17,11 @@ _NAMES = [
     "Kp", "Ki", "perm", "iperm", "Mp", "Mi", "Mtarget", "prod_ptr", "prod_a", "prod_b", "src", "sn_c0", "sn_r",
     "sn_rowptr", "sn_rows", "sn_parent", "sn_level", "sn_Loff", "sn_Uoff", "sn_uoff", "child_ptr", "child_idx", "dense_cols", "late_cols",
     "rel_ptr", "rel", "level_ptr", "level_sn", "Ar_ptr", "Ar_col", "Ar_src", "Kc_y",
+    "bnd_row", "bnd_col", "row_ext", "ent_ext", "cut_ptr", "cut_row", "cut_ent",
 ]
 _SCALARS = [
     "N", "n", "m", "my", "n_late", "n_late_rows", "saddle", "nnzK", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzL", "nnzL_true", "flops",
-    "flops_dense", "nprod", "max_r", "max_w", "max_u", "t_order", "t_symbolic", "t_total",
+    "flops_dense", "nprod", "max_r", "max_w", "max_u", "t_order", "t_symbolic", "t_total", "N_ext", "n_bounds",
 ]
 
 
@@ -62,7 +63,7 @@ class Plan:
                 rc = lib.hipfact_plan_scalar(p, name.encode(), C.byref(v))
                 assert rc == 0, name
                 setattr(self, name, v.value)
-            for name in ("N", "n", "m", "my", "n_late", "n_late_rows", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzK", "nprod"):
+            for name in ("N", "n", "m", "my", "n_late", "n_late_rows", "nsuper", "nlevels", "L_size", "U_size", "u_size", "nnzK", "nprod", "N_ext", "n_bounds"):
                 setattr(self, name, int(getattr(self, name)))
             self.saddle = bool(self.saddle)
         finally:
@@ -87,6 +88,11 @@ class EmulFactor:
     def __init__(self, P: Plan, Kx: np.ndarray):
         self.P = P
         self.Kx = np.asarray(Kx, dtype=np.float64)
+        # active bounds eliminated by the analysis (Plan::n_bounds): the plan is that of the reduced matrix K', whose
+        # entries are a subset of the caller's (ent_ext); the caller's values are kept for the cut entries A'_B
+        self.Kx_ext = self.Kx
+        if P.n_bounds > 0:
+            self.Kx = self.Kx_ext[P.ent_ext]
         L = np.zeros(max(P.L_size, 1))
         U = np.zeros(max(P.U_size, 1))
         mv = _mvals(P, self.Kx)
@@ -171,9 +177,29 @@ class EmulFactor:
         return y
 
     def solve(self, b):
-        """Solve K z = b (original ordering)."""
+        """Solve K z = b (the caller's K, original ordering)."""
         P = self.P
         b = np.asarray(b, dtype=np.float64)
+        if P.n_bounds == 0:
+            return self._solve_plan(b)
+        # x_B = beta; K' [x; y'] = [b_x; b_y' - A'_B beta]; y_B = b_B - beta - A'_B^T y'  (plan.h)
+        n = P.n
+        beta = b[n + P.bnd_row]
+        cut_of = np.repeat(np.arange(P.n_bounds), np.diff(P.cut_ptr))
+        cut_val = self.Kx_ext[P.cut_ent]
+        b2 = np.concatenate([b[:n], b[n + P.row_ext]])
+        b2[n:] -= np.bincount(P.cut_row, weights=cut_val * beta[cut_of], minlength=len(P.row_ext))
+        z2 = self._solve_plan(b2)
+        z = np.empty(P.N_ext)
+        z[:n] = z2[:n]
+        z[P.bnd_col] = beta
+        z[n + P.row_ext] = z2[n:]
+        z[n + P.bnd_row] = b[P.bnd_col] - beta - np.bincount(cut_of, weights=cut_val * z2[n + P.cut_row], minlength=P.n_bounds)
+        return z
+
+    def _solve_plan(self, b):
+        """Solve K' z = b for the matrix the plan was built for."""
+        P = self.P
         if not P.saddle:
             t = b[P.perm]
             y = self.solve_m(t)

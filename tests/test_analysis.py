@@ -87,7 +87,8 @@ def test_saddle_plan(hipfact_lib, n, m, kind, frac):
     vi, ci, _ = synth.working_set_all_rows(n, m, frac, 1)
     N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
     P = _check(hipfact_lib, N, cp, ri, vx)
-    assert P.saddle and P.n == n and P.m == N - n
+    assert P.saddle and P.n == n and P.m == N - n - P.n_bounds and P.N_ext == N
+    assert P.n_bounds == int((np.asarray(vi) >= 0).sum())  # every active bound is eliminated in front of the analysis
     _structure_invariants(P)
 
 
@@ -121,7 +122,7 @@ def test_only_active_bounds(hipfact_lib):
     vi = np.array([0, -1, 1, -1], dtype=np.int32)
     N, cp, ri, vx = synth.kkt_lower_from_jacobian(sp.csc_matrix((0, 4)), vi, np.zeros(0, np.int32))
     P = _check(hipfact_lib, N, cp, ri, vx)
-    assert P.saddle and P.m == 2
+    assert P.saddle and P.m == 0 and P.n_bounds == 2 and P.nsuper == 0  # (bounds only: nothing left to factor)
 
 
 def test_full_working_set(hipfact_lib):
@@ -256,9 +257,11 @@ def test_late_variables_and_hub_rows(hipfact_lib, case):
     n, m, J, vi, ci = _late_case(case)
     N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
     P = Plan(hipfact_lib, N, cp, ri, vx)
-    assert P.saddle and P.n == n and P.my == N - n and P.m == P.my + P.n_late
+    assert P.saddle and P.n == n and P.my == N - n - P.n_bounds and P.m == P.my + P.n_late
+    # (bound_on_late_variable: the bound is eliminated in front of the analysis, build_plan_bounds - the fixed variable's
+    # column holds nothing any more and is no late variable, its unit row is no row of the reduced matrix)
     want_late = {"late1": 1, "late3_partial": 3, "late70": 70, "hub_row": 0, "hub_rows_and_late": 4,
-                 "row_only_in_late_columns": 2, "bound_on_late_variable": 3}[case]
+                 "row_only_in_late_columns": 2, "bound_on_late_variable": 2}[case]
     assert P.n_late == want_late and len(P.late_cols) == want_late
     if case == "hub_row":
         assert P.n_late_rows == 1
@@ -267,7 +270,7 @@ def test_late_variables_and_hub_rows(hipfact_lib, case):
     if case == "row_only_in_late_columns":
         assert P.n_late_rows == 2
     if case == "bound_on_late_variable":
-        assert P.n_late_rows >= 1  # the unit row of the bound has its only entry in a late column
+        assert P.n_bounds == int((np.asarray(vi) >= 0).sum()) and P.n_late_rows == 0
     _structure_invariants(P)
     K = synth.kkt_full_matrix(N, cp, ri, vx)
     F = EmulFactor(P, vx)
@@ -289,7 +292,9 @@ def test_late_variables_and_hub_rows(hipfact_lib, case):
         for k in range(first_late):
             r = P.perm[k]
             assert r < P.my
-            if r >= nb:  # a constraint row (unit rows of bounds come first in K)
+            if P.n_bounds:  # (rows of the reduced matrix: back to the caller's numbering, unit rows of bounds come first in K)
+                r = int(P.row_ext[r])
+            if r >= nb:  # a constraint row
                 row = A.indices[A.indptr[r - nb]:A.indptr[r - nb + 1]] if ci is None else None
                 if row is not None:
                     assert (~latec[row]).any()
@@ -311,3 +316,34 @@ def test_late_elimination_keeps_the_tree_short_at_scale(hipfact_lib):
         assert P.nlevels <= base.nlevels + 2, (P.nlevels, base.nlevels)
         assert P.nnzL_true <= 2.0 * mmd, (P.nnzL_true, mmd)
         assert P.t_total < 1.0
+
+
+def test_active_bounds_do_not_deepen_the_tree(hipfact_lib):
+    """VERDICT round 4, item 2 (working_set.c:139, standard_aug_jac.c:163-185: the unit rows of active bounds come first
+    in every working set).  Left in the graph of S = A A^T a bound on x_j is adjacent to every row that holds x_j; at
+    SURVEY's config-4 size the exact-pattern analysis went from 11 levels / 595 fronts to 28 / 3539 at 10 % active
+    bounds and 46 / 7498 at 20 %.  build_plan_bounds eliminates them in front of the analysis: the tree is that of
+    the constraint rows with the fixed variables' columns masked, whatever path asks for the plan."""
+    n, m = 100000, 50000
+    J = synth.banded_jacobian(n, m, 20, 200, 0)
+    base = None
+    for frac in (0.0, 0.1, 0.3):
+        vi, ci, _ = synth.working_set_all_rows(n, m, frac, 0)
+        N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+        P = Plan(hipfact_lib, N, cp, ri, vx)
+        nb = int((np.asarray(vi) >= 0).sum()) if vi is not None else 0
+        assert P.n_bounds == nb and P.N_ext == N and P.my == m
+        if base is None:
+            base = (P.nlevels, P.nsuper, P.flops)
+        assert P.nlevels <= base[0] + 1 and P.nsuper <= 1.1 * base[1] and P.flops <= 1.05 * base[2], (frac, P.nlevels, P.nsuper)
+    # ... and the reduced plan solves the caller's K (emulator, moderate size, a third of the bounds active)
+    n, m = 3000, 1500
+    J = synth.banded_jacobian(n, m, 12, 120, 3)
+    vi, ci, _ = synth.working_set_all_rows(n, m, 0.3, 3)
+    N, cp, ri, vx = synth.kkt_lower_from_jacobian(J, vi, ci)
+    P = Plan(hipfact_lib, N, cp, ri, vx)
+    assert P.n_bounds == int((np.asarray(vi) >= 0).sum()) > 0.25 * n
+    K = synth.kkt_full_matrix(N, cp, ri, vx)
+    b = np.random.default_rng(5).standard_normal(N)
+    z = EmulFactor(P, vx).solve(b)
+    assert np.abs(K @ z - b).max() <= 1e-9 * max(1.0, np.abs(b).max())

@@ -946,7 +946,7 @@ def test_reduced_matrix_is_the_sparse_product(fact):
     scipy, in working-set row order - sparse where the reference stores the whole lower triangle."""
     from sleqp_amd.sparse import SleqpMat
 
-    fact.set_option("superset_vtable", 0)  # the exact pattern of K: no working-set maps between S and the caller
+    fact.set_option("exact_pattern", 1)  # the pattern of K itself: no working-set maps between S and the caller
     for n, m, kind, frac in [(7, 3, "u", 0.3), (300, 150, "b", 0.1), (2000, 900, "u", 0.05)]:
         J, vi, ci, W = _problem(n, m, kind, frac, 5)
         N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
@@ -1695,6 +1695,56 @@ def test_full_size_properties(fact, workload):
     fact.solve(SleqpVec.from_raw(rhs))
     x = fact.solution_raw(0, n)
     assert np.abs(A @ x - rhs[n:]).max() <= 1e-9 * max(1.0, np.abs(x).max()) * np.abs(A).sum(axis=1).max()
+
+
+@pytest.mark.parametrize("boundary", ["vtable", "assembly", "vtable_exact"])
+def test_full_size_with_active_bounds(fact, boundary):
+    """SURVEY 8(d)'s variant "10 % random active bounds" at BASELINE configs[3]'s full size.
+    The reference puts the unit rows of active bounds first in every working set (working_set.c:139, 167-168;
+    standard_aug_jac.c:163-185); here they are eliminated in front of the analysis on every boundary - the row
+    dictionary behind the plain vtable, the device assembly, and the exact-rows path of superset_vtable = 0 - so the
+    tree keeps the depth of the constraint rows' own.  Against the oracle's sparse LDL^T and the residual; then the set
+    of active bounds changes by +-1 % of n per call with a single analysis."""
+    from sleqp_amd.fact import StandardAugJac
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 100000, 50000
+    J = synth.banded_jacobian(n, m, 20, 200, 0)
+    rng = np.random.default_rng(5)
+    if boundary == "vtable_exact":
+        fact.set_option("superset_vtable", 0)
+    aug = StandardAugJac(n, fact, device_assembly=(boundary == "assembly"))
+
+    def one(vi, ci, against_oracle):
+        aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)
+        N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
+        if boundary == "assembly":  # the device's own fill_aug_jac, bit for bit
+            assert np.array_equal(aug.K.cols, kc) and np.array_equal(aug.K.rows, kr) and np.array_equal(aug.K.data, kd)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        b = rng.standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert scaled_residual(K, z, b) <= RESID_TOL
+        if against_oracle:
+            assert rel_err(z, oracle.OracleLdl(N, kc, kr, kd).solve(b)) <= 1e-8
+
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.1, 0)
+    one(vi, ci, True)
+    assert fact.info("maps_on") == 1 and fact.info("nlevels") <= 12 and fact.info("analyses") == 1
+    active = vi >= 0
+    for it in range(3):  # 1 % of the variables leave their bounds, 1 % others hit theirs
+        leave = rng.choice(np.flatnonzero(active), n // 100, replace=False)
+        enter = rng.choice(np.flatnonzero(~active), n // 100, replace=False)
+        active[leave] = False
+        active[enter] = True
+        vi = np.full(n, -1, dtype=np.int32)
+        vi[active] = np.arange(int(active.sum()), dtype=np.int32)
+        ci = (int(active.sum()) + np.arange(m)).astype(np.int32)
+        one(vi, ci, False)
+        if boundary != "vtable_exact":  # (no reuse across patterns there: every changed pattern is analysed on its own rows)
+            assert fact.info("analyses") == 1, it
+        assert fact.info("nlevels") <= 12
+    assert fact.info("dataflow_fallbacks") == 0
 
 
 def test_full_size_krylov_loops(fact):
