@@ -167,6 +167,8 @@ struct TopChunk {
 constexpr int TOP_CB = 8;
 // LDS doubles of a k_solve_tree workgroup; a top-block item needs nT + 1024 + (nT + 1 + sources + 1) / 2 of them
 constexpr int TOP_LDS = 7 * 1024 + 512;
+constexpr int SPMV_NNZ = 2048;  // k_spmv_stream: entries per row block / workgroup
+constexpr int SPMV_T = 256;
 constexpr int TREE_LDS = 2 * 1024 + 8;  // k_solve_tree without a top block (dynamic LDS, doubles)
 struct TopBlockIn {
   int nT, ntf, ntb;

@@ -396,6 +396,29 @@ def test_spmv_kernels(fact):
     # empty matrix
     E = SpMat(fact, SleqpMat(3, 4))
     assert np.array_equal(E.mult_vec(np.ones(4)), np.zeros(3))
+    # the streaming kernel (k_spmv_stream: row blocks through LDS, the default from 4 M entries on) on ragged matrices:
+    # empty rows, rows longer than a block, block boundaries at odd entries, an odd number of entries; bitwise deterministic
+    fact.set_option("spmv_stream_min", 0)
+    for (r, c, dens, seed) in [(1, 1, 1.0, 1), (50, 80, 0.3, 2), (3000, 2500, 0.02, 3), (700, 9000, 0.2, 4), (5000, 40, 0.6, 5)]:
+        M = sp.random(r, c, density=dens, random_state=seed, format="lil")
+        if r > 100:
+            M[7, :] = 1.0       # a row / a column longer than a block
+            M[:, 3] = 2.0
+            M[11, :] = 0.0      # an empty row
+        M = sp.csc_matrix(M)
+        M.eliminate_zeros()
+        M.sort_indices()
+        S = SpMat(fact, SleqpMat.from_scipy(M))
+        x, yv = rng.standard_normal(c), rng.standard_normal(r)
+        assert fact.info("spmv_stream") == 1
+        got = S.mult_vec(x)
+        assert rel_err(got, M @ x) <= 1e-13 and np.array_equal(got, S.mult_vec(x))
+        got_t = S.mult_vec_trans(SleqpVec.from_raw(yv), eps=0.0).to_raw()
+        assert rel_err(got_t, M.T @ yv) <= 1e-13
+        fact.set_option("spmv_stream", 0)  # ... and against the lanes-per-row kernel
+        assert rel_err(S.mult_vec(x), got) <= 1e-13
+        fact.set_option("spmv_stream", 1)
+        S.free()
 
 
 def test_assembly_bit_exact(fact):
