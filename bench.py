@@ -1080,6 +1080,9 @@ def main():
                 "frac_incl": (bytes_per_launch + extra) / avg_s / 1e9 / HBM_PEAK_GBS,
                 "note": "solve panels S = [X; -L21 X] of all fronts are built inside this launch (3.7 GFLOP fp64 MFMA); "
                         "with spanel_fold=0 they are a launch of their own (k_build_solve_panels, ~98 us) and this one is ~35 us shorter"}
+        # counters of the run's own handle: anything but zero means a fallback path was taken inside the timed region
+        for key in ("dataflow_fallbacks", "dense_fallbacks", "vtable_retries", "solve_timeouts"):
+            out[key] = int(fact.info(key))
         fact.free()
         if world == 1 and not args.no_extras:
             out["boundary"] = boundary_bench(J, N, cp, ri, vx, b, 30, local_rank)
@@ -1103,6 +1106,19 @@ def main():
             out["measured_ceilings"] = measured_ceilings(f"cuda:{local_rank}")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, cp, ri, vx, b)
+        # the figures a reader looks for first, once more at the END of the line (a driver that keeps the tail of a long
+        # line keeps these)
+        so = out.get("solve_only", {})
+        bd = out.get("boundary", {}) if isinstance(out.get("boundary"), dict) else {}
+        out["summary"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "factor_only_ms": out.get("factor_only_ms"),
+                          "solve_only_ms": so.get("ms_per_solve"), "roofline_frac": out.get("roofline", {}).get("frac"),
+                          "dominant_kernel": out.get("roofline", {}).get("kernel"),
+                          "dominant_kernel_us": out.get("roofline", {}).get("avg_launch_us"),
+                          "boundary_rate": bd.get("rate"), "boundary_ms_per_unit": bd.get("ms_per_unit"),
+                          "boundary_solve_plus_solution_ms": bd.get("solve_plus_solution_ms"),
+                          "sqp_iteration_ms": out.get("sqp_iteration", {}).get("ms") if isinstance(out.get("sqp_iteration"), dict) else None,
+                          "dataflow_fallbacks": out.get("dataflow_fallbacks"), "dense_fallbacks": out.get("dense_fallbacks"),
+                          "vtable_retries": out.get("vtable_retries"), "solve_timeouts": out.get("solve_timeouts")}
         print(json.dumps(out), flush=True)
     rep.close()
 

@@ -17,7 +17,10 @@ def run(opts):
     f.set_option("refine_steps", 0)
     for kv in opts.split():
         f.set_option(kv.split("=")[0], float(kv.split("=")[1]))
-    f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    try:
+        f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    except Exception as e:  # (a schedule under test may leave a factor the check refuses: still compared)
+        print('   set_matrix:', str(e)[:120])
     f.synchronize()
     L = np.empty(P.L_size, dtype=np.float64)
     assert lib.hipfact_debug_copy(f._h, b"L", L.ctypes.data_as(C.c_void_p), L.nbytes) == 0
@@ -35,7 +38,8 @@ ref, rSPf, rSPb, ritems = run(sys.argv[1] if len(sys.argv) > 1 else "factor_top_
 loff2front = {int(P.sn_Loff[s]): s for s in range(P.nsuper)}
 for trial in range(int(os.environ.get("TRIALS", "3"))):
     got, gSPf, gSPb, gitems = run(sys.argv[2] if len(sys.argv) > 2 else "factor_top_fused=64")
-    assert np.array_equal(ritems, gitems)
+    if not np.array_equal(ritems, gitems):
+        print('   (solve items differ)')
     # solve panels, item by item (offsets spf / spb lead the item; the front from its panel offset)
     off = gitems[:, :16].copy().view(np.int64).reshape(-1, 2)
     # Loff sits behind: 2 ll, 2 ll, 4 int, 4 int, 4 ll, 4 int -> byte 112
@@ -68,6 +72,10 @@ for trial in range(int(os.environ.get("TRIALS", "3"))):
             rows_bad = np.nonzero((d > 1e-11 * sc).any(axis=1))[0]
             cols_bad = np.nonzero((d > 1e-11 * sc).any(axis=0))[0]
             bad.append((int(P.sn_level[s]), s, ws, r, d.max() / sc, int(i), int(k), rows_bad.min(), rows_bad.max(), len(rows_bad), cols_bad.min(), cols_bad.max(), len(cols_bad)))
+            if len(bad) == 1 and os.environ.get("SHOW"):
+                np.set_printoptions(precision=4, linewidth=200)
+                i0 = int(rows_bad.min())
+                print("ref rows", i0, ":\n", a[i0:i0 + 4, :8], "\ngot:\n", g[i0:i0 + 4, :8], "\ncount of zeros in got panel:", int((g == 0).sum()), "of", g.size, " nan:", int(np.isnan(g).sum()))
     print(f"trial {trial}: {len(bad)} fronts differ")
     for t in sorted(bad)[:12]:
         print("   level %d front %d w %d r %d  rel %.1e at (%d,%d)  bad rows %d..%d (%d)  bad cols %d..%d (%d)" % t)

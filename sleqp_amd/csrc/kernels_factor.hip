@@ -22,6 +22,7 @@
 //   kernels_front_pivot.inc   pivot block of a front: blocked LDL^T as free-running waves, posted tiles
 //   kernels_front_update.inc  panel solve, Schur tiles, the per-level kernels
 //   kernels_front_fused.inc   panel solve + Schur tile of a front as one role of the dataflow launch
+//   kernels_front_whole.inc   a whole front in one workgroup (the wide bottom levels of the dataflow launch)
 //   kernels_solve_level.inc   level-scheduled / one-launch-per-direction solves (fallback)
 //   kernels_factor_top.inc    k_factor_top: the upper levels of the factorisation as one dataflow launch
 //   kernels_solve_wide.inc    wide fronts of the fallback solves
@@ -40,6 +41,7 @@ namespace hipfact {
 #include "kernels_front_pivot.inc"
 #include "kernels_front_update.inc"
 #include "kernels_front_fused.inc"
+#include "kernels_front_whole.inc"
 #include "kernels_solve_panels.inc"
 #include "kernels_factor_top.inc"
 }  // namespace hipfact
