@@ -544,6 +544,12 @@ def structural_robustness_bench(J4, local_rank):
             r["factor_plus_solve_vs_base"] = r["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
             r["active_bounds"] = int((vi >= 0).sum())
             out[name] = r
+        # wide separators: a PDE-constrained 2-D grid at config 4's size - separators of ~g
+        # columns become chains of fronts of at most 128 columns
+        rg = device_unit(synth.grid2d_jacobian(224, 0), local_rank)
+        rg["factor_plus_solve_vs_base"] = rg["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
+        rg["unit_per_gflop_vs_base"] = (rg["factor_plus_solve_ms"] / max(rg["flops"], 1.0)) / (base["factor_plus_solve_ms"] / max(base["flops"], 1.0))
+        out["grid2d_g224"] = rg
         J2 = synth.banded_jacobian(20000, 10000, 20, 200, 0)
         b2 = device_unit(J2, local_rank)
         out["n2e4_base"] = b2

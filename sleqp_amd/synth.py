@@ -33,6 +33,28 @@ def banded_jacobian(n: int, m: int, nz_per_row: int = 20, width: int = 200, seed
     return J
 
 
+def grid2d_jacobian(g: int, seed: int = 0) -> sp.csc_matrix:
+    """PDE-constrained 2-D family: a g x g grid of states y and as many controls u,
+    one constraint per cell - the 5-point Laplacian of the states plus the cell's control, ``A y + u = f`` with
+    variable coefficients.  n = 2 g^2, m = g^2; ``J J^T`` is a 13-point stencil on the grid, so the separators of a nested
+    dissection are ~g (2 g near the top) columns wide: wider than the 128 columns of one front."""
+    rng = np.random.default_rng(seed)
+    cell = np.arange(g * g, dtype=np.int64).reshape(g, g)
+    rows, cols, vals = [], [], []
+    for di, dj, base in ((0, 0, 4.0), (1, 0, -1.0), (-1, 0, -1.0), (0, 1, -1.0), (0, -1, -1.0)):
+        src = cell[max(0, -di):g - max(0, di), max(0, -dj):g - max(0, dj)].ravel()
+        dst = cell[max(0, di):g - max(0, -di), max(0, dj):g - max(0, -dj)].ravel()
+        rows.append(src)
+        cols.append(dst)
+        vals.append(base * (1.0 + 0.1 * rng.random(src.size)))
+    rows.append(cell.ravel())            # the cell's control
+    cols.append(g * g + cell.ravel())
+    vals.append(1.0 + 0.1 * rng.random(g * g))
+    J = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(g * g, 2 * g * g))
+    J.sort_indices()
+    return J
+
+
 def uniform_jacobian(n: int, m: int, nz_per_row: int = 10, seed: int = 0) -> sp.csc_matrix:
     """Config 3 family: ``nz_per_row`` entries per row at uniform random distinct columns."""
     rng = np.random.default_rng(seed)

@@ -1770,6 +1770,87 @@ def test_full_size_with_active_bounds(fact, boundary):
     assert fact.info("dataflow_fallbacks") == 0
 
 
+def test_top_block_under_graded_conditioning(fact):
+    """VERDICT round 4 (parity, soft spot ii): the single-product top block of the solve applies an explicit inverse
+    Z = S_T^-1 while the residual is only taken on every k-th solve (8, 16, 32, 64 after checks that pass).  A size at
+    which the block forms (n = 2e4, m = 1e4: nine levels), graded families on it - row scalings over six decades,
+    nearly parallel rows, column scalings -, 150 solves per factorisation so that the interval reaches its maximum:
+    EVERY solution is checked here on the host (scaled residual on the caller's K), the ones the device did not check
+    included."""
+    import scipy.sparse as sp
+
+    from sleqp_amd.sparse import SleqpMat
+
+    n, m = 20000, 10000
+    J0 = synth.banded_jacobian(n, m, 20, 200, 5)
+    rng = np.random.default_rng(8)
+
+    def near_parallel(J, eps, k=40):
+        Jr = sp.csr_matrix(J)
+        extra = Jr[rng.choice(Jr.shape[0], k, replace=False)].copy()
+        extra.data = extra.data * (1.0 + eps * rng.standard_normal(extra.data.size))
+        out = sp.vstack([Jr, extra]).tocsc()
+        out.sort_indices()
+        return out
+
+    d6 = np.logspace(0, 6, m)
+    rng.shuffle(d6)
+    dc = np.logspace(0, 3, n)
+    rng.shuffle(dc)
+    cases = [("rowscale_1e6", sp.csc_matrix(sp.diags(d6) @ J0)), ("parallel_1e-4", near_parallel(J0, 1e-4)),
+             ("colscale_1e3", sp.csc_matrix(J0 @ sp.diags(dc)))]
+    for name, J in cases:
+        J.sort_indices()
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        worst, checked0 = 0.0, fact.info("num_refined")
+        for k in range(150):
+            b = rng.standard_normal(N)
+            fact.solve(b)
+            worst = max(worst, scaled_residual(K, fact.solution_raw(0, N), b))
+        assert fact.info("top_block_active") == 1 and fact.info("top_block_cols") > 500, name
+        # (the equilibrated backward error the device controls is <= 1e-12 / kappa-scaled; on the caller's K a graded
+        # family loses what its row scales span - the bound below is what the per-front sweep gives as well)
+        fact.set_option("top_block_after", 1 << 30)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        ref = 0.0
+        for k in range(20):
+            b = rng.standard_normal(N)
+            fact.solve(b)
+            ref = max(ref, scaled_residual(K, fact.solution_raw(0, N), b))
+        fact.set_option("top_block_after", 2)
+        assert worst <= max(4.0 * ref, RESID_TOL), (name, worst, ref)
+        assert fact.info("dataflow_fallbacks") == 0
+
+
+def test_wide_separators_of_a_2d_grid(fact):
+    """a PDE-constrained 2-D grid (5-point Laplacian states + controls).  J J^T is a 13-point
+    stencil, the separators of the dissection are wider than one front (128 columns) and become chains of fronts:
+    against the oracle's sparse LDL^T and the residual, the AugJac solves against the sparse product formulas."""
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    for g in (40, 96):
+        J = synth.grid2d_jacobian(g, 1)
+        m, n = J.shape
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("max_w") <= 128
+        b = np.random.default_rng(g).standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert scaled_residual(K, z, b) <= RESID_TOL
+        assert rel_err(z, oracle.OracleLdl(N, kc, kr, kd).solve(b)) <= 1e-8
+        gvec = np.zeros(N)
+        gvec[:n] = np.random.default_rng(3).standard_normal(n)
+        fact.solve(SleqpVec.from_raw(gvec))
+        Pg = fact.solution_raw(0, n)
+        A = J.tocsr()
+        assert np.abs(A @ Pg).max() <= 1e-9 * np.abs(A).sum(axis=1).max() * np.abs(gvec).max()
+        assert fact.info("dataflow_fallbacks") == 0
+
+
 def test_full_size_krylov_loops(fact):
     """BASELINE.json configs[3] (n = 1e5, m = 5e4) under the device-resident Krylov loops of the EQP step, with the
     banded Hessian of the bench: the device-controlled CG against the host-driven loop (iteration count, step), the
