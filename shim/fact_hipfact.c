@@ -21,6 +21,7 @@
 #include "fact_hipfact.h"
 
 #include <assert.h>
+#include <math.h>
 
 #ifndef HIPFACT_STANDALONE
 #include "defs.h"
@@ -210,7 +211,31 @@ hipfact_fact_solution(void* fact_data,
 
   hipfact_log_events(data, "solution");
 
-  SLEQP_CALL(sleqp_vec_set_from_raw(sol, slice, end - begin, zero_eps));
+  /* sleqp_vec_set_from_raw (vec.c:71-103) walks the slice twice - count, then push - which is 57 us of the 250 us a
+   * solve + solution costs at n = 1e5.  One walk: the capacity of the dense case is reserved (the vector keeps it
+   * across calls, and projections / duals are dense), entries are pushed exactly as vec.c:88-100 does, in
+   * ascending order with the same zero test */
+  {
+    const int dim = end - begin;
+    SLEQP_CALL(sleqp_vec_clear(sol));
+    SLEQP_CALL(sleqp_vec_resize(sol, dim));
+    SLEQP_CALL(sleqp_vec_reserve(sol, dim));
+
+    double* data = sol->data;
+    int* indices = sol->indices;
+    int k        = 0;
+
+    for (int i = 0; i < dim; ++i)
+    {
+      const double v = slice[i];
+
+      data[k]    = v;
+      indices[k] = i;
+      k += !(fabs(v) <= zero_eps);
+    }
+
+    sol->nnz = k;
+  }
 
   return SLEQP_OKAY;
 }

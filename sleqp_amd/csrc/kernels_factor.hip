@@ -41,7 +41,9 @@ namespace hipfact {
 #include "kernels_front_pivot.inc"
 #include "kernels_front_update.inc"
 #include "kernels_front_fused.inc"
-#include "kernels_front_whole.inc"
+#ifdef HIPFACT_WHOLE_ROLE  // (an experiment that is compiled on request only: its 17 accumulator tiles per wave push the whole
+#include "kernels_front_whole.inc"  // dataflow kernel to 256 registers and every role of it got ~3 % slower)
+#endif
 #include "kernels_solve_panels.inc"
 #include "kernels_factor_top.inc"
 }  // namespace hipfact
