@@ -71,6 +71,13 @@ struct TopFItem {
   int sidx, scount;     // Schur: index among / number of the Schur workgroups of the front
   int post;             // the pivot workgroup posts inv(L11) tile by tile, the panel workgroups poll for it (no flag hop)
   long long xoff;       // the front's wp x wp slot in the arena of posted pivot blocks
+  // The parent's PIVOT block only reads the leading k x k corner of a child's update matrix (k = the child's update
+  // rows that are pivot columns of the parent): the Schur workgroups whose tiles touch that corner ("head") come first
+  // in the level's order and count themselves in a second counter (hdone), and the parent's pivot workgroup waits for
+  // that one - its chain runs beside the child's remaining tiles.  Panel / Schur / fused roles of the parent still wait
+  // for the whole child (they read the rest, and the update arena is reused on that assumption).
+  int head;               // Schur: this workgroup's tile(s) touch the head corner
+  int wait_head[MAXCH];   // pivot: head workgroups of each child (0: wait for the whole child, wait_cnt)
 };
 
 // one front of the single-launch top-of-tree solve kernels (one uniform load per workgroup)
