@@ -62,6 +62,15 @@ INST_CG(4)
 INST_CG(16)
 INST_CG(64)
 #undef INST_CG
+#define INST_CGH(L)                                                                                                    \
+  template __global__ void k_cg_head<L>(int, const CgCtl*, CgCtl*, const double*, int, int, const int*, const int*,    \
+                                        const double*, const int*, const int*, const double*, const double*, double*,  \
+                                        double*, const double*, const double*, double*);
+INST_CGH(1)
+INST_CGH(4)
+INST_CGH(16)
+INST_CGH(64)
+#undef INST_CGH
 #define INST_LZ(L)                                                                                                  \
   template __global__ void k_lz_spmv_dot<L>(int, const LzCtl*, const int*, const int*, const double*, const int*,   \
                                             const int*, const double*, const double*, double*, double*);
