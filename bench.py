@@ -923,9 +923,9 @@ def main():
         t_cg = time.perf_counter() - t0
         extras["eqp_cg_device"] = {"iterations": its, "ms_per_iteration": t_cg * 1e3 / max(its, 1),
                                    "device_runs": fact.info("cg_device_runs"), "device_fallbacks": fact.info("cg_device_fallbacks"),
-                                   "note": "explicit Hessian in HBM, loop controlled on the device: 4 launches per iteration (product + "
-                                           "dots | tests + z, r | projection with x update and r.g | beta + d), host looks at the "
-                                           "control block every 8 iterations"}
+                                   "note": "explicit Hessian in HBM, loop controlled on the device: 3 launches per iteration (tests + "
+                                           "z, r | projection with x update and r.g | beta + d + B d by recurrence from B g, with "
+                                           "the dots), host looks at the control block every 8 iterations"}
         # (warm-up with the same iteration cap: the Lanczos basis and the coefficient buffers are sized by it)
         fact.tr_solve(Hd, grad, 1e6, method=1, stat_tol=1e-30, max_iter=20)
         lz_dev_its0 = fact.info("lz_device_iterations")

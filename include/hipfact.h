@@ -112,7 +112,11 @@ int hipfact_condition(hipfact_handle* h, double* condition);
 /* ---- device-resident variants (no PCIe in the hot loop) ----------------- */
 
 /* Numeric refactorisation with new values already in HBM (same pattern as the
- * last hipfact_set_matrix).  `d_vals` is a device pointer to nnz doubles. */
+ * last hipfact_set_matrix).  `d_vals` is a device pointer to nnz doubles in the
+ * layout of THAT matrix (the caller's K, unit rows of active bounds included:
+ * the backend scatters them into its own structure).  HIPFACT_ESTATE when the
+ * active plan was assembled from a Jacobian (hipfact_assemble_kkt is its
+ * refactorisation). */
 int hipfact_refactor_device(hipfact_handle* h, const double* d_vals);
 
 /* Solve with the right-hand side resident in HBM (`d_rhs`, N doubles) and
