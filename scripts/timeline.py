@@ -73,7 +73,7 @@ def run():
     print("# per level of the dataflow launch (us): fronts, pivots waited (first..last), pivots done (last), panels published (last), Schur published (last)")
     for l in range(int(f.info("factor_top_level")), P.nlevels):
         m_ = lev[front] == l
-        pv, pn, sc = m_ & ((role == 0) | (role == 5)), m_ & (role == 1), m_ & ((role == 2) | (role == 4) | (role == 5))
+        pv, pn, sc = m_ & ((role == 0) | (role == 5) | (role == 6)), m_ & (role == 1), m_ & ((role == 2) | (role == 4) | (role == 5))
         # (a stamp that was never taken - a workgroup beyond the trace slots, a branch without that mark - is 0 in the raw
         # record, i.e. far below zero after the shift to the launch's first stamp: left out, not averaged in)
         def mx(a):
@@ -91,12 +91,12 @@ def run():
     for l in range(int(f.info("factor_top_level")), P.nlevels):
         m_ = (lev[front] == l) & (role != 3)
         parts = []
-        for rr, nm in ((0, "pivot"), (1, "panel"), (2, "schur"), (4, "fused"), (5, "whole")):
+        for rr, nm in ((0, "pivot"), (1, "panel"), (2, "schur"), (4, "fused"), (5, "whole"), (6, "pivot+panel")):
             k_ = m_ & (role == rr) & (tt[:, 1] > 0) & (tt[:, 2] > 0)
             if k_.any():
                 parts.append(f"{nm} {int(k_.sum()):4d}: wait {np.mean(tt[k_, 1] - tt[k_, 0]):6.1f}  work {np.mean(tt[k_, 2] - tt[k_, 1]):5.1f}  publish {np.mean(tt[k_, 3] - tt[k_, 2]):4.1f}")
         print(f"  level {l:2d}  " + "   ".join(parts))
-    names = ["pivot", "panel", "schur", "spanl", "fused", "whole"]
+    names = ["pivot", "panel", "schur", "spanl", "fused", "whole", "pv+pn"]
     sp = role == 3
     if sp.any():
         # solve-panel items (role 3): stamped at start only (slot 0); their end is not on the record, so the window

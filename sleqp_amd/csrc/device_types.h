@@ -59,7 +59,8 @@ struct PairDesc {
 // one workgroup of the single-launch top-of-tree factorisation kernel
 struct TopFItem {
   FrontItem it;
-  int role;   // 0 pivot, 1 panel, 2 Schur, 3 solve panels, 4 panel rows + Schur tile in one (kernels_front_fused.inc)
+  int role;   // 0 pivot, 1 panel, 2 Schur, 3 solve panels, 4 panel rows + Schur tile in one (kernels_front_fused.inc),
+              // 5 whole front (experiment), 6 pivot block + panel rows in one
   int front;  // index of the front's counters
   int part2;  // Schur: the second team's tile
   int nwait;  // number of children
