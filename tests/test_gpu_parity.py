@@ -1567,6 +1567,72 @@ def test_dense_chain_lookahead_gives_the_same_factor(fact):
     fact.set_option("refine_steps", 1)
 
 
+def test_device_resident_loop_of_one_solve_per_factorisation():
+    """A loop `refactor_device; solve_device` with no synchronising entry point in between (bench.py's unit) never
+    reaches the second-solve peek that drops the correction pass from the solve graphs; the refactorisation looks at
+    the last verdict that has come back instead (`factor_hint_peek`).  Well conditioned K: the pass is dropped after the
+    first verdict is back, every solution still meets the tolerance.  A graded K (row scales over eight decades) in the
+    same loop on a K with nearly parallel rows: if the first pass alone does not meet a quarter of the tolerance the
+    pass stays, and `check` (a synchronising entry point) finishes whatever was left."""
+    import scipy.sparse as sp
+    import torch
+
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    fact = HipFact(device=0)  # (a handle of its own: no plan state of earlier tests)
+    n, m = 20000, 10000
+    J0 = synth.banded_jacobian(n, m, 20, 200, 5)
+    rng = np.random.default_rng(3)
+    Jr = sp.csr_matrix(J0)  # nearly parallel rows: another pattern (a plan state of its own), kappa ~ 1e7
+    extra = Jr[rng.choice(Jr.shape[0], 40, replace=False)].copy()
+    extra.data = extra.data * (1.0 + 1e-7 * rng.standard_normal(extra.data.size))
+    Jg = sp.vstack([Jr, extra]).tocsc()
+    Jg.sort_indices()
+    for name, J, expect_drop in (("plain", J0, True), ("parallel_1e-7", Jg, None)):
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        fact.set_option("refine_steps", 1)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        d_vals = torch.from_numpy(np.ascontiguousarray(kd)).cuda()
+        b = rng.standard_normal(N)
+        d_rhs = torch.from_numpy(b).cuda()
+        d_sol = torch.empty_like(d_rhs)
+        inline = []
+        for it in range(6):
+            fact.refactor_device(d_vals.data_ptr())
+            inline.append(int(fact.info("refine_inline")))
+            fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+            torch.cuda.synchronize()  # (the device is done; the library has not been asked anything)
+        assert inline[0] == 1, (name, inline)  # nothing has come back for this plan yet
+        if expect_drop:
+            assert inline[-1] == 0, (name, inline)
+        passes0 = fact.info("num_passes")
+        fact.check()
+        x = d_sol.cpu().numpy()
+        # (against what the host boundary gives on the same K: nearly parallel rows leave the caller's residual above
+        # the tolerance of the equilibrated system the device controls)
+        fact.solve(b)
+        ref = scaled_residual(K, fact.solution_raw(0, N), b)
+        assert scaled_residual(K, x, b) <= max(4.0 * ref, RESID_TOL), (name, scaled_residual(K, x, b), ref)
+        if not expect_drop and inline[-1] == 0:
+            # the hint said "well conditioned": then the device's own verdict of the last solve must say so too
+            assert fact.info("num_passes") == passes0 and fact.info("last_iters") == 0, (name, inline)
+        assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
+        if expect_drop:
+            g = HipFact(device=0)  # without the peek the loop keeps the pass
+            g.set_option("factor_hint_peek", 0)
+            g.set_matrix(SleqpMat(N, N, kc, kr, kd))
+            for it in range(3):
+                g.refactor_device(d_vals.data_ptr())
+                assert int(g.info("refine_inline")) == 1, name
+                g.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
+                torch.cuda.synchronize()
+            g.check()
+            g.free()
+    fact.free()
+
+
 def test_solve_sequence_with_changing_right_hand_sides(fact):
     """The single-launch solve sweeps exchange vectors element by element through slots that the
     opposite sweep puts back to a sentinel.  A slot that was not put back would hand a value of
