@@ -386,7 +386,7 @@ def boundary_bench(J, N, cp, ri, vx, b, steps, local_rank):
     t0 = time.perf_counter()
     unit()  # cold: analysis + uploads + graph capture
     t_cold = time.perf_counter() - t0
-    for _ in range(3):
+    for _ in range(10):  # (the copy engine and the host's staging path take a few units to reach their steady rate)
         unit()
     t0 = time.perf_counter()
     for _ in range(steps):
