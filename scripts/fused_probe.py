@@ -22,7 +22,10 @@ for g in groups:
     for kv in g.split():
         k, v = kv.split("=")
         f.set_option(k, float(v))
-    f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    try:
+        f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+    except Exception as e:  # (a timing experiment may leave a factor the check refuses: still timed)
+        print("   set_matrix:", str(e)[:100], flush=True)
     if os.environ.get("STEPWISE"):
         # residual after the first factorisation and after each of a few refactorisations
         out = []

@@ -1574,13 +1574,29 @@ def test_device_resident_loop_of_one_solve_per_factorisation():
     first verdict is back, every solution still meets the tolerance.  A graded K (row scales over eight decades) in the
     same loop on a K with nearly parallel rows: if the first pass alone does not meet a quarter of the tolerance the
     pass stays, and `check` (a synchronising entry point) finishes whatever was left."""
+    import ctypes as C
+
     import scipy.sparse as sp
-    import torch
 
     from sleqp_amd.fact import HipFact
     from sleqp_amd.sparse import SleqpMat
 
     fact = HipFact(device=0)  # (a handle of its own: no plan state of earlier tests)
+    # device buffers straight from the HIP runtime the library is linked against (torch brings a runtime of its own,
+    # which does not find the device once this one is initialised)
+    hip = C.CDLL("libamdhip64.so")
+
+    def to_device(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        return p
+
+    def to_host(p, n):
+        out = np.empty(n)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes), 2) == 0
+        return out
+
     n, m = 20000, 10000
     J0 = synth.banded_jacobian(n, m, 20, 200, 5)
     rng = np.random.default_rng(3)
@@ -1594,22 +1610,22 @@ def test_device_resident_loop_of_one_solve_per_factorisation():
         K = synth.kkt_full_matrix(N, kc, kr, kd)
         fact.set_option("refine_steps", 1)
         fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
-        d_vals = torch.from_numpy(np.ascontiguousarray(kd)).cuda()
+        d_vals = to_device(np.ascontiguousarray(kd, dtype=np.float64))
         b = rng.standard_normal(N)
-        d_rhs = torch.from_numpy(b).cuda()
-        d_sol = torch.empty_like(d_rhs)
+        d_rhs = to_device(b)
+        d_sol = to_device(np.zeros(N))
         inline = []
         for it in range(6):
-            fact.refactor_device(d_vals.data_ptr())
+            fact.refactor_device(d_vals.value)
             inline.append(int(fact.info("refine_inline")))
-            fact.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
-            torch.cuda.synchronize()  # (the device is done; the library has not been asked anything)
+            fact.solve_device(d_rhs.value, d_sol.value)
+            assert hip.hipDeviceSynchronize() == 0  # (the device is done; the library has not been asked anything)
         assert inline[0] == 1, (name, inline)  # nothing has come back for this plan yet
         if expect_drop:
             assert inline[-1] == 0, (name, inline)
         passes0 = fact.info("num_passes")
         fact.check()
-        x = d_sol.cpu().numpy()
+        x = to_host(d_sol, N)
         # (against what the host boundary gives on the same K: nearly parallel rows leave the caller's residual above
         # the tolerance of the equilibrated system the device controls)
         fact.solve(b)
@@ -1624,12 +1640,14 @@ def test_device_resident_loop_of_one_solve_per_factorisation():
             g.set_option("factor_hint_peek", 0)
             g.set_matrix(SleqpMat(N, N, kc, kr, kd))
             for it in range(3):
-                g.refactor_device(d_vals.data_ptr())
+                g.refactor_device(d_vals.value)
                 assert int(g.info("refine_inline")) == 1, name
-                g.solve_device(d_rhs.data_ptr(), d_sol.data_ptr())
-                torch.cuda.synchronize()
+                g.solve_device(d_rhs.value, d_sol.value)
+                assert hip.hipDeviceSynchronize() == 0
             g.check()
             g.free()
+        for p_ in (d_vals, d_rhs, d_sol):
+            assert hip.hipFree(p_) == 0
     fact.free()
 
 
