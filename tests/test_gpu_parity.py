@@ -1232,6 +1232,7 @@ def test_right_hand_side_formed_inside_the_solve_launch(fact):
     """The forward items of the single-launch solve form their own rows of t = A^ b_x - D b_y (16 lanes per
     row, the partial sums and the shuffle tree of k_rhs_saddle) instead of reading what a launch in front of
     them left: same bits, with and without working-set maps, first pass and correction passes."""
+    fact.set_option("top_block_breakeven", 0)  # (bits are compared ACROSS factorisations: the top block forms at the same solve in each)
     from sleqp_amd.sparse import SleqpMat
 
     J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 4)
@@ -1291,6 +1292,7 @@ def test_deferred_refinement_verdict(fact):
     themselves, and a refactorisation flushes it first (it is judged against that factorisation's pivots).
     Same solutions, same backward errors and pass counts as with a verdict launch behind every solve, over
     solves, refactorisations with different values and checks in between."""
+    fact.set_option("top_block_breakeven", 0)  # (bits are compared ACROSS factorisations: the top block forms at the same solve in each)
     from sleqp_amd.sparse import SleqpMat
 
     J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 6)
@@ -1417,6 +1419,7 @@ def test_x_update_inside_the_solve_launch(fact):
     same shuffle tree, same bits - with active bounds (working-set maps), over a sequence of right-hand sides
     (the exchange slots alternate by launch parity, now advanced by the launch's own last workgroup) and with
     correction passes (accumulating mode)."""
+    fact.set_option("top_block_breakeven", 0)  # (bits are compared ACROSS factorisations: the top block forms at the same solve in each)
     from sleqp_amd.fact import StandardAugJac
     from sleqp_amd.sparse import SleqpMat, SleqpVec
 
@@ -1457,6 +1460,7 @@ def test_residual_checked_on_every_kth_solve_only(fact):
     (refine_check_every, default 8; the reference's MA57 path never checks, fact_ma57.c:18): same bits as with a
     check behind every solve, the checked ones report the same backward error, and an ill-conditioned factorisation
     (correction passes in the graph) keeps checking every solve."""
+    fact.set_option("top_block_breakeven", 0)  # (bits are compared ACROSS factorisations: the top block forms at the same solve in each)
     from sleqp_amd.sparse import SleqpMat
 
     J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 6)
@@ -1501,6 +1505,7 @@ def test_dense_chain_levels_as_small_dataflow_launches(fact):
     fronts of the two-launch solves exchange posted data instead of flags.  Agreement with the per-level kernels to
     rounding (substitution against the posted L11 / product with inv(L11)), bitwise reproducible over repeated
     factorisations (the posted slots are refilled with the sentinel each time)."""
+    fact.set_option("top_block_breakeven", 0)  # (bits are compared ACROSS factorisations: the top block forms at the same solve in each)
     from sleqp_amd.sparse import SleqpMat
 
     J = synth.uniform_jacobian(3000, 1500, 10, 9)  # dense Schur complement: a chain of single-front levels
@@ -1649,6 +1654,40 @@ def test_device_resident_loop_of_one_solve_per_factorisation():
         for p_ in (d_vals, d_rhs, d_sol):
             assert hip.hipFree(p_) == 0
     fact.free()
+
+
+def test_top_block_forms_when_it_pays(fact):
+    """Forming the top block costs ~0.4 ms and saves ~9 us per solve.  A fresh plan forms it at the second solve (as
+    if many solves were to follow); a factorisation that follows one with few solves waits until it has seen
+    `top_block_breakeven` solves itself; one that follows a long one forms it at the second solve again.  Solutions
+    agree with and without the block to the residual tolerance."""
+    from sleqp_amd.sparse import SleqpMat
+
+    J, vi, ci, _ = _problem(20000, 10000, "b", 0.0, 6)
+    N, kc, kr, kd = oracle.fill_aug_jac(20000, 10000, J.indptr, J.indices, J.data, vi, ci)
+    K = synth.kkt_full_matrix(N, kc, kr, kd)
+    rng = np.random.default_rng(2)
+    be = 48
+
+    def solves(k):
+        for _ in range(k):
+            b = rng.standard_normal(N)
+            fact.solve(b)
+            assert scaled_residual(K, fact.solution_raw(0, N), b) <= RESID_TOL
+
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    solves(3)
+    assert fact.info("top_block_cols") > 0 and fact.info("top_block_active") == 1  # fresh plan
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))  # ... whose previous factorisation saw three solves
+    solves(3)
+    assert fact.info("top_block_active") == 0
+    solves(be - 4)
+    assert fact.info("top_block_active") == 0
+    solves(2)
+    assert fact.info("top_block_active") == 1
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))  # ... and now one that saw 49
+    solves(2)
+    assert fact.info("top_block_active") == 1
 
 
 def test_solve_sequence_with_changing_right_hand_sides(fact):
