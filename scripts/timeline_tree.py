@@ -38,7 +38,7 @@ def build():
                   f"#define TRS(slot) if (threadIdx.x == 0) g_st[blockIdx.x * 8 + (slot)] = wall_clock64()\n"
                   "typedef double d4_t __attribute__((ext_vector_type(4)));", 1)
     a = s.index("__device__ __forceinline__ void dev_solve_fwd(")
-    b = s.index("// Solve panels of one front from its factored panel")
+    b = s.index("void k_solve_tree(", a)  # (the launch itself: both sweeps' device functions sit in front of it)
     seg = s[a:b]
     # forward
     seg = seg.replace("  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here", "  TRS(1);\n  // staged row tid (front row fr): own right-hand side and, per child, which of its update rows lands here", 1)
@@ -46,11 +46,12 @@ def build():
     seg = seg.replace("      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n}", "      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n  TRS(3);\n}", 1)
     # backward
     seg = seg.replace("  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", "  TRS(1);\n  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", 1)
-    seg = seg.replace("  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();", "  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();\n  TRS(2);", 1)
-    seg = seg.replace("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n}", "      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n  TRS(3);\n}", 1)
-    seg = seg.replace("  const int par = *epoch & 1;", "  TRS(0);\n  const int par = *epoch & 1;", 1)
-    assert seg.count("TRS(") == 7, seg.count("TRS(")
+    seg = seg.replace("    if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  }\n  __syncthreads();", "    if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  }\n  __syncthreads();\n  TRS(2);", 1)
+    seg = seg.replace("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n", "      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n  TRS(3);\n", 1)
+    assert seg.count("TRS(") == 6, seg.count("TRS(")
     s = s[:a] + seg + s[b:]
+    assert s.count("  const int par = *epoch & 1;") >= 1
+    s = s.replace("  const int par = *epoch & 1;", "  TRS(0);\n  const int par = *epoch & 1;", 1)
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "kernels_solve.hip")
     t = open(h).read()
@@ -93,7 +94,7 @@ def run():
     item_dt = np.dtype([("spf", "<i8"), ("spb", "<i8"), ("uoff", "<i8"), ("rowoff", "<i8"), ("c0", "<i4"), ("w", "<i4"), ("r", "<i4"),
                         ("nchild", "<i4"), ("Qf", "<i4"), ("Ef", "<i4"), ("Pb", "<i4"), ("Eb", "<i4"), ("c_uoff", "<i8", 4),
                         ("c_invoff", "<i4", 4), ("Loff", "<i8"), ("xbegin", "<i4"), ("xend", "<i4"), ("a0", "<i4"), ("a1", "<i4"),
-                        ("sl", "<i4"), ("nsl", "<i4"), ("poff", "<i8")])
+                        ("sl", "<i4"), ("nsl", "<i4"), ("poff", "<i8"), ("plevel", "<i4"), ("pad_", "<i4")])
     raw = np.empty(2 * nf * item_dt.itemsize, dtype=np.uint8)  # forward order, then backward order
     lib.hipfact_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     assert lib.hipfact_debug_copy(f._h, b"sitems", raw.ctypes.data_as(C.c_void_p), raw.nbytes) == 0
