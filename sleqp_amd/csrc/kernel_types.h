@@ -17,6 +17,8 @@ constexpr int RL = 16;  // lanes per row of A^_p in the right-hand side product
 constexpr int ST = 1024;  // threads per workgroup
 constexpr int SPB = 512;
 constexpr int ZT = 64;   // tile of k_top_syrk (top block of the solve as one product)
+constexpr int ZC = 32;   // ... pivots per staged chunk
+constexpr int ZS = 512;  // ... pivots per segment of a tile's sum (k_top_syrk_mfma / _reduce)
 constexpr int CG_BLOCKS = 2048;  // most blocks (= partial sums) of the product kernel: one pass over the rows per block when they suffice
 constexpr int CG_CHUNK = 8;  // iterations per graph launch (= per look of the host at the control block)
 
