@@ -46,15 +46,15 @@ def build():
         ("      post_f64(uvec + T.uoff + a0 + j, f[w + j] + s2);\n    }\n  }\n}", None, "TAIL")])
     s = segment(s, "__device__ __forceinline__ void dev_solve_bwd(", "// ---- top block (device_types.h: TopBlockIn)", [
         ("  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", "  TRS(1);\n"),
-        ("  if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  __syncthreads();", None, "\n  TRS(2);"),
-        ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n}", None, "TAIL")])
+        ("    if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  }\n  __syncthreads();", None, "\n  TRS(2);"),
+        ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n", None, "\n  TRS(3);\n")])
     s = patch(s, [("  const int par = *epoch & 1;  // constant while anybody reads it", "  TRS(0);\n")])
     # the top block as one product (dev_top_one): entry | prefetch issued | lists in LDS | gathered | posted
     s = segment(s, "__device__ __forceinline__ void dev_top_one(", "// Z = X_T^T D_T^-1 X_T from the dense X_T", [
         ("  if (tid < nr) {\n    sent_f64(ysol_prev + B.tpos[I.r0 + tid]);", "  TRS(1);\n"),
         ("  constexpr int GK = 6;", "  TRS(4);\n"),
         ("  __syncthreads();\n  double acc = 0.0;", None, "\n  TRS(2);"),
-        ("      y[k] = s2;\n      post_f64(ysol + k, s2);\n    }\n  }\n}", None, "TAIL")])
+        ("      y[k] = s2;\n      post_f64(ysol + k, s2);\n    }\n  }\n", None, "  TRS(3);\n")])
     s = s.replace("  __syncthreads();\n  double acc = 0.0;\n  TRS(2);", "  __syncthreads();\n  TRS(2);\n  double acc = 0.0;")
     open(p, "w").write(s)
     h = os.path.join(SCRATCH, "kernels_solve.hip")
