@@ -63,7 +63,7 @@ INST_MVALS(long long, false)
   template __global__ void k_front_pivot<CH>(const FrontItem*, double*, double*, int*, const int*, const int*,     \
                                              const PullDesc*, int, const unsigned*);                                \
   template __global__ void k_front_panel<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
-                                             const PullDesc*, int, const unsigned*, int);                           \
+                                             const PullDesc*, int, const unsigned*);                                \
   template __global__ void k_front_schur<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
                                              const PullDesc*, int);
 INST_FRONT(true)
