@@ -172,7 +172,7 @@ struct TopChunk {
   int front;  // TopFront
   int j0;     // first of (at most TOP_CB) columns of that front
 };
-constexpr int TOP_CB = 8;
+constexpr int TOP_CB = 4;  // (k_top_inverse: 2 / 4 / 8 / 16 / 32 columns per workgroup measured 156 / 105 / 146 / - / - us, the solve slower with 16 and 32)
 // LDS doubles of a k_solve_tree workgroup; a top-block item needs nT + 1024 + (nT + 1 + sources + 1) / 2 of them
 constexpr int TOP_LDS = 7 * 1024 + 512;
 constexpr int SPMV_NNZ = 2048;  // k_spmv_stream: entries per row block / workgroup
