@@ -274,6 +274,32 @@ def load_traffic(kernel_name, workload=None):
         "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernels sha %s" % pmc["_kernels_sha16"]
 
 
+def load_level_timeline(workload=None):
+    """Per-level spans (us) of the dataflow launch from the committed in-kernel timeline
+    (profiles/<tag>_timeline_factor_top.txt, scripts/timeline.py: an instrumented build, one launch): from the first pivot
+    workgroup of a level having its children to the level's last update matrix being published.  Context beside the
+    plan's per-level entries, not an input of `roofline`."""
+    if workload not in (None, "banded_n1e5_m5e4"):
+        return None
+    try:
+        txt = open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_timeline_factor_top.txt")).read()
+    except OSError:
+        return None
+    out = {}
+    for line in txt.splitlines():
+        t = line.split()
+        if len(t) > 4 and t[0] == "level" and t[2] == "fronts" and "waited" in t:
+            try:
+                start = float(t[t.index("waited") + 1])
+                ends = [float(t[t.index(k) + 1]) for k in ("done", "published") if k in t]
+                ends += [float(t[i + 1]) for i, k in enumerate(t) if k == "published" and i + 1 < len(t)]
+                ends = [e for e in ends if e == e]
+                out[int(t[1])] = {"from_us": start, "to_us": max(ends), "span_us": max(ends) - start}
+            except (ValueError, IndexError):
+                continue
+    return out or None
+
+
 def load_spmv_traffic(workload=None):
     """HBM bytes per launch of the three sparse products, from PMC passes that run ONE product each
     (`bench.py --spmv-only NAME` under rocprofv3 --pmc; the products share a kernel template)."""
@@ -987,12 +1013,36 @@ def main():
         #   fronts that kernel family processes; the split phases A-D share their fronts' bytes.  The stored
         #   panel entries are scaled down to structural entries (nnzL_true / nnzL).
         true_frac = fact.info("nnzL_true") / max(fact.info("nnzL"), 1.0)
+        # per tree level, from the plan: fronts, stored entries of L, row indices, dense flops; which launch processes it
+        ftop = int(fact.info("factor_top_level"))
+        levels = []
+        for l in range(int(fact.info("nlevels"))):
+            levels.append({"level": l, "fronts": int(fact.info(f"level_fronts_{l}")), "entries": fact.info(f"level_ent_{l}"),
+                           "block_entries": fact.info(f"level_blk_{l}"),
+                           "rows": fact.info(f"level_rows_{l}"), "flops": fact.info(f"level_flops_{l}"),
+                           "launch": "k_factor_top" if l >= ftop else "per-level kernels"})
+        for lv in levels:
+            lv["algorithmic_bytes"] = 16 * lv["entries"] * true_frac + 4 * lv["rows"]
+        timeline_us = load_level_timeline(args.workload)
+        if timeline_us:
+            for lv in levels:
+                if lv["level"] in timeline_us:
+                    lv["timeline_us"] = timeline_us[lv["level"]]
         if dom == "factor":
             step_bytes = 16 * fact.info("ent_fused") * true_frac + 4 * fact.info("rows_fused")
-        elif dom in ("factorA", "factorB", "factorC", "factorD", "factorT"):
-            # the per-level kernels and the single-launch top-of-tree kernel share the fronts' bytes by time
-            fam = sum(prof[k]["ms_per_step"] for k in ("factorA", "factorB", "factorC", "factorD", "factorT") if k in prof)
-            step_bytes = (16 * fact.info("ent_split") * true_frac + 4 * fact.info("rows_split")) * prof[dom]["ms_per_step"] / fam
+        elif dom == "factorT":
+            # the dataflow launch: the SURVEY 8(d) bytes of the fronts IT processes (the levels from factor_top_level up)
+            step_bytes = sum(lv["algorithmic_bytes"] for lv in levels if lv["level"] >= ftop)
+        elif dom in ("factorA", "factorB", "factorC", "factorD"):
+            # per-level kernels of the levels below the dataflow launch.  Of a front's 16 B / entry + 4 B / row the pivot
+            # kernel writes the w (w + 1) / 2 block entries and they are read once (16 B each), the panel kernel writes the
+            # u w panel entries (8 B), the Schur kernel reads them (8 B) and the row indices; the scatter assembly (A) moves
+            # no entry of L.
+            below = [lv for lv in levels if lv["level"] < ftop]
+            blk = sum(lv["block_entries"] for lv in below) * true_frac
+            pan = sum(lv["entries"] - lv["block_entries"] for lv in below) * true_frac
+            step_bytes = {"factorA": 0.0, "factorB": 16 * blk, "factorC": 8 * pan,
+                          "factorD": 8 * pan + 4 * sum(lv["rows"] for lv in below)}[dom]
         elif dom in ("fwd", "bwd"):
             step_bytes = sbytes / 2
         elif dom == "tree":
@@ -1039,7 +1089,11 @@ def main():
                          "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_basis": "structural nnz(L) (column counts); stored dense panels: x%.3f" % (1.0 / true_frac),
-                         "avg_launch_us": prof[dom]["avg_launch_us"]},
+                         "avg_launch_us": prof[dom]["avg_launch_us"],
+                         "recompute": "achieved = sum of levels[l].algorithmic_bytes over the levels this kernel processes "
+                                      "(levels[l].launch) / avg_launch_us; algorithmic_bytes = 16 B x entries x "
+                                      "(nnz_L / nnz_L_stored) + 4 B x rows (SURVEY 8(d))"},
+            "levels": levels,
             "kernels": prof,
             "solve_only": {"solves_per_s": 1.0 / t_solve, "ms_per_solve": t_solve * 1e3, "top_block": top_block,
                            "passes_per_solve": passes, "algorithmic_GBps": sbytes * passes / t_solve / 1e9,

@@ -246,6 +246,32 @@ int hipfact_tr_solve(hipfact_handle* h, int method, hipfact_spmat* hess, hipfact
                      const double* gradient, double trust_radius, double rel_tol, int max_iter, double* newton_step,
                      double* tr_dual, int* iterations);
 
+/* The rest of the SleqpTRCallbacks contract (tr/tr_types.h:9-29): the `time_limit` argument of the solve slot and
+ * the rayleigh slot (:18-20).
+ *   time_limit    in, seconds from the call's entry, < 0 (SLEQP_NONE) = none.  The host loops look at the clock where
+ *                 the reference does (steihaug_solver.c:297-310: top of every iteration; trlib_solver.c:631-636:
+ *                 behind every completed iteration), the device-controlled loops whenever the host looks at their
+ *                 control block (every 8 iterations).
+ *   timed_out     out, 1 when the limit ended the iteration: the call still returns HIPFACT_OK and newton_step is the
+ *                 iterate reached (feasible, inside the region); the SLEQP side returns SLEQP_ABORT_TIME
+ *                 (steihaug_solver.c:490-492, trlib_solver.c:641-644), shim/tr_hipfact.c
+ *   min_rayleigh  out, extremes of d.Bd / d.d over the CG directions, starting from 1 / 1 (steihaug_collect_rayleigh,
+ *   max_rayleigh  steihaug_solver.c:150-182, 229-230); GLTR: of p.Hp / p.Mp over the equivalent CG directions while the
+ *                 Lanczos tridiagonal is positive definite, of q.Hq / q.Mq = delta_k beyond (what trlib_rayleigh reads
+ *                 from trlib's work array, trlib_solver.c:654-662); newton.c:328-343 reads them */
+typedef struct hipfact_tr_extra
+{
+  double time_limit;
+  int timed_out;
+  double min_rayleigh;
+  double max_rayleigh;
+} hipfact_tr_extra;
+
+/* hipfact_tr_solve with the extras above (extra == NULL: hipfact_tr_solve itself). */
+int hipfact_tr_solve_ex(hipfact_handle* h, int method, hipfact_spmat* hess, hipfact_hess_prod_fn prod, void* user,
+                        const double* gradient, double trust_radius, double rel_tol, int max_iter, double* newton_step,
+                        double* tr_dual, int* iterations, hipfact_tr_extra* extra);
+
 /* Host-only: the tridiagonal trust-region subproblem of GLTR (exposed for the tests).
  * min 1/2 h'Th + gamma0 e1'h, ||h|| <= radius; delta[0..k) diagonal, gamma[1..k) off-diagonal. */
 int hipfact_tridiag_tr(int k, const double* delta, const double* gamma, double gamma0, double radius, double* h,

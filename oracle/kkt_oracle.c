@@ -574,10 +574,30 @@ static void project_dense(OracleFact* f, int n, const double* v, double* out)
  * STAT_TOL (1e-6, settings.c), tolerance_factor 1e-2 (steihaug_solver.c:21),
  * max_iter = MAX_NEWTON_ITERATIONS (100, settings.c:62; -1 = none).
  * Returns the number of CG iterations, or ORACLE_ERROR. */
+/* ... and the extremes of the Rayleigh quotients d.Bd / d.d it collects on the way (steihaug_collect_rayleigh,
+ * steihaug_solver.c:150-171, called right behind the product at :282; both start at 1, :229-230) - what
+ * steihaug_solver_rayleigh (:173-185) hands to newton.c:328-343.  Either pointer may be NULL. */
+int oracle_steihaug_solve_rayleigh(OracleFact* f, int n, const int* hc, const int* hr, const double* hx,
+                                   const double* gradient, double trust_radius, double stat_tol, int max_iter,
+                                   double* newton_step, double* min_rayleigh_out, double* max_rayleigh_out);
+
 int oracle_steihaug_solve(OracleFact* f, int n, const int* hc, const int* hr, const double* hx,
                           const double* gradient, double trust_radius, double stat_tol, int max_iter,
                           double* newton_step)
 {
+  return oracle_steihaug_solve_rayleigh(f, n, hc, hr, hx, gradient, trust_radius, stat_tol, max_iter, newton_step, NULL,
+                                        NULL);
+}
+
+int oracle_steihaug_solve_rayleigh(OracleFact* f, int n, const int* hc, const int* hr, const double* hx,
+                                   const double* gradient, double trust_radius, double stat_tol, int max_iter,
+                                   double* newton_step, double* min_rayleigh_out, double* max_rayleigh_out)
+{
+  double min_rayleigh = 1., max_rayleigh = 1.;
+  if (min_rayleigh_out)
+    *min_rayleigh_out = min_rayleigh;
+  if (max_rayleigh_out)
+    *max_rayleigh_out = max_rayleigh;
   const double rel_tol    = stat_tol * 1e-2;
   const double rel_tol_sq = rel_tol * rel_tol;
   double* buf             = (double*)calloc((size_t)6 * (n > 0 ? n : 1), sizeof(double));
@@ -611,6 +631,16 @@ int oracle_steihaug_solve(OracleFact* f, int n, const int* hc, const int* hr, co
     {
       free(buf);
       return ORACLE_ERROR;
+    }
+    {
+      /* steihaug_collect_rayleigh */
+      const double dir_normsq = dotn(n, d, d);
+      if (dir_normsq != 0.)
+      {
+        const double cur_rayleigh = dotn(n, d, Bd) / dir_normsq;
+        min_rayleigh              = cur_rayleigh < min_rayleigh ? cur_rayleigh : min_rayleigh;
+        max_rayleigh              = cur_rayleigh > max_rayleigh ? cur_rayleigh : max_rayleigh;
+      }
     }
     const double dBd = dotn(n, d, Bd);
     if (dBd <= 0.)
@@ -657,6 +687,10 @@ int oracle_steihaug_solve(OracleFact* f, int n, const int* hc, const int* hr, co
       d[i] = -g[i] + beta * d[i];
   }
   free(buf);
+  if (min_rayleigh_out)
+    *min_rayleigh_out = min_rayleigh;
+  if (max_rayleigh_out)
+    *max_rayleigh_out = max_rayleigh;
   return iteration;
 }
 

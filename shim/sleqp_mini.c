@@ -747,15 +747,24 @@ struct SleqpTRSolver
   int refcount;
   SleqpTRCallbacks callbacks;
   void* data;
+  double time_limit; /* tr/tr_solver.c:13 */
 };
+
+SLEQP_RETCODE
+sleqp_tr_solver_set_time_limit(SleqpTRSolver* solver, double time_limit)
+{
+  solver->time_limit = time_limit; /* tr/tr_solver.c:18-21 */
+  return SLEQP_OKAY;
+}
 
 SLEQP_RETCODE
 sleqp_tr_solver_create(SleqpTRSolver** star, SleqpTRCallbacks* callbacks, void* solver_data)
 {
   SLEQP_CALL(sleqp_malloc(star));
   (*star)->refcount  = 1;
-  (*star)->callbacks = *callbacks;
-  (*star)->data      = solver_data;
+  (*star)->callbacks  = *callbacks;
+  (*star)->data       = solver_data;
+  (*star)->time_limit = SLEQP_NONE; /* tr/tr_solver.c:47 */
   return SLEQP_OKAY;
 }
 
@@ -763,7 +772,7 @@ SLEQP_RETCODE
 sleqp_tr_solver_solve(SleqpTRSolver* solver, SleqpAugJac* jacobian, const SleqpVec* multipliers, const SleqpVec* gradient,
                       SleqpVec* newton_step, double trust_radius, double* tr_dual)
 {
-  return solver->callbacks.solve(jacobian, multipliers, gradient, newton_step, trust_radius, tr_dual, SLEQP_NONE,
+  return solver->callbacks.solve(jacobian, multipliers, gradient, newton_step, trust_radius, tr_dual, solver->time_limit,
                                  solver->data);
 }
 

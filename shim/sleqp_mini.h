@@ -395,6 +395,8 @@ SLEQP_WARNUNUSED SLEQP_RETCODE
 sleqp_tr_solver_solve(SleqpTRSolver* solver, SleqpAugJac* jacobian, const SleqpVec* multipliers,
                       const SleqpVec* gradient, SleqpVec* newton_step, double trust_radius, double* tr_dual);
 SLEQP_WARNUNUSED SLEQP_RETCODE
+sleqp_tr_solver_set_time_limit(SleqpTRSolver* solver, double time_limit); /* tr/tr_solver.h:26 */
+SLEQP_RETCODE
 sleqp_tr_solver_current_rayleigh(SleqpTRSolver* solver, double* min_rayleigh, double* max_rayleigh);
 SLEQP_WARNUNUSED SLEQP_RETCODE
 sleqp_tr_solver_release(SleqpTRSolver** star);

@@ -53,6 +53,10 @@ struct SleqpHipfactTR
 
   double* dense_gradient; /* num_variables */
   double* dense_step;     /* num_variables */
+
+  /* of the last solve (steihaug_solver.c:229-230: 1 / 1 before the first) */
+  double min_rayleigh;
+  double max_rayleigh;
 };
 
 static uint64_t
@@ -105,10 +109,11 @@ hipfact_tr_free(void** star)
 static SLEQP_RETCODE
 hipfact_tr_rayleigh(double* min_rayleigh, double* max_rayleigh, void* solver_data)
 {
-  /* not tracked on the device; 1 / 1 is what steihaug_solver_solve starts from (:229-230) */
-  (void)solver_data;
-  *min_rayleigh = 1.;
-  *max_rayleigh = 1.;
+  /* steihaug_solver_rayleigh (steihaug_solver.c:173-185) / trlib_rayleigh (trlib_solver.c:654-662): the extremes the
+   * last solve collected, here on the device (hipfact_tr_extra) */
+  SleqpHipfactTR* solver = (SleqpHipfactTR*)solver_data;
+  *min_rayleigh          = solver->min_rayleigh;
+  *max_rayleigh          = solver->max_rayleigh;
   return SLEQP_OKAY;
 }
 
@@ -154,7 +159,6 @@ tr_callback_solve(SleqpAugJac* jacobian,
 {
   SleqpHipfactTR* solver = (SleqpHipfactTR*)solver_data;
   (void)jacobian; /* its factorisation is the bound handle */
-  (void)time_limit;
 
   const int num_variables = sleqp_problem_num_vars(solver->problem);
 
@@ -170,19 +174,25 @@ tr_callback_solve(SleqpAugJac* jacobian,
   solver->multipliers     = multipliers;
   solver->callback_status = SLEQP_OKAY;
 
-  int iterations   = 0;
-  const int status = hipfact_tr_solve(solver->handle,
-                                      solver->method,
-                                      solver->hessian,
-                                      solver->hessian ? NULL : hess_prod_callback,
-                                      solver,
-                                      solver->dense_gradient,
-                                      trust_radius,
-                                      solver->rel_tol,
-                                      solver->max_iter,
-                                      solver->dense_step,
-                                      tr_dual,
-                                      &iterations);
+  int iterations = 0;
+  /* time_limit: seconds or SLEQP_NONE (-1), tr/tr_solver.c:18-21,47 - the same convention as hipfact_tr_extra */
+  hipfact_tr_extra extra = {.time_limit = time_limit, .timed_out = 0, .min_rayleigh = 1., .max_rayleigh = 1.};
+  const int status       = hipfact_tr_solve_ex(solver->handle,
+                                         solver->method,
+                                         solver->hessian,
+                                         solver->hessian ? NULL : hess_prod_callback,
+                                         solver,
+                                         solver->dense_gradient,
+                                         trust_radius,
+                                         solver->rel_tol,
+                                         solver->max_iter,
+                                         solver->dense_step,
+                                         tr_dual,
+                                         &iterations,
+                                         &extra);
+
+  solver->min_rayleigh = extra.min_rayleigh;
+  solver->max_rayleigh = extra.max_rayleigh;
 
   solver->multipliers = NULL;
 
@@ -198,6 +208,12 @@ tr_callback_solve(SleqpAugJac* jacobian,
   }
 
   SLEQP_CALL(sleqp_vec_set_from_raw(newton_step, solver->dense_step, num_variables, solver->zero_eps));
+
+  if (extra.timed_out)
+  {
+    /* steihaug_solver.c:490-492, trlib_solver.c:641-644 */
+    return SLEQP_ABORT_TIME;
+  }
 
   return SLEQP_OKAY;
 }
@@ -307,6 +323,9 @@ sleqp_hipfact_tr_solver_create(SleqpTRSolver** star,
   SLEQP_CALL(sleqp_malloc(&solver));
 
   *solver = (SleqpHipfactTR){0};
+
+  solver->min_rayleigh = 1.;
+  solver->max_rayleigh = 1.;
 
   solver->problem = problem;
   SLEQP_CALL(sleqp_problem_capture(solver->problem));

@@ -95,6 +95,7 @@ struct XupdIn {
 };
 struct CgCtl {
   double rg, z_nrm_sq, rel_tol_sq, rad_sq, alpha, beta, tau;
+  double ray_min, ray_max;  // smallest / largest d.Bd / d.d seen (steihaug_collect_rayleigh, steihaug_solver.c:150-182); start at 1
   int state;  // 0 running, 1 interior solution (|r.g| small), 2 boundary, 3 negative curvature, 4 iteration cap
   int stop, apply, it, max_iter, pad;
 };

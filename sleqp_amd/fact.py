@@ -156,11 +156,13 @@ class HipFact:
         return sp.csc_matrix((vx[:nnz.value], ri[:nnz.value], cp), shape=(m, m))
 
     def tr_solve(self, hess, gradient, trust_radius: float, method: int = 1, stat_tol: float = 1e-6,
-                 max_iter: int = 100):
-        """hipfact_tr_solve: method 0 = projected Steihaug CG (tr/steihaug_solver.c), 1 = generalised Lanczos
+                 max_iter: int = 100, time_limit: float = -1.0):
+        """hipfact_tr_solve_ex: method 0 = projected Steihaug CG (tr/steihaug_solver.c), 1 = generalised Lanczos
         (what trlib runs, tr/trlib_solver.c).  `hess` is an SpMat (explicit lower-triangular Hessian in HBM)
         or a callable d -> H d on host arrays (the matrix-free SLEQP_FUNC_HESS_PROD).  Returns
-        (step, tr_dual, iterations)."""
+        (step, tr_dual, iterations); `time_limit` (seconds, < 0 = SLEQP_NONE) and the rest of the
+        SleqpTRCallbacks contract (tr/tr_types.h:9-29) are left in `self.last_tr`: timed_out, min_rayleigh,
+        max_rayleigh."""
         g = np.ascontiguousarray(gradient, dtype=np.float64)
         n = g.size
         step = np.empty_like(g)
@@ -178,9 +180,12 @@ class HipFact:
                     return -1
 
             mat, cb = None, cb_type(_prod)
-        self._check(self._lib.hipfact_tr_solve(self._h, int(method), mat, cb, None, _ptr(g), float(trust_radius),
-                                               stat_tol * 1e-2, int(max_iter), _ptr(step), C.byref(dual),
-                                               C.byref(its)))
+        extra = TrExtra(float(time_limit), 0, 1.0, 1.0)
+        self._check(self._lib.hipfact_tr_solve_ex(self._h, int(method), mat, cb, None, _ptr(g), float(trust_radius),
+                                                  stat_tol * 1e-2, int(max_iter), _ptr(step), C.byref(dual),
+                                                  C.byref(its), C.byref(extra)))
+        self.last_tr = {"timed_out": bool(extra.timed_out), "min_rayleigh": extra.min_rayleigh,
+                        "max_rayleigh": extra.max_rayleigh}
         return step, dual.value, its.value
 
     def free(self):
@@ -193,6 +198,12 @@ class HipFact:
             self.free()
         except Exception:
             pass
+
+
+class TrExtra(C.Structure):
+    """hipfact_tr_extra (include/hipfact.h)"""
+    _fields_ = [("time_limit", C.c_double), ("timed_out", C.c_int), ("min_rayleigh", C.c_double),
+                ("max_rayleigh", C.c_double)]
 
 
 class SpMat:

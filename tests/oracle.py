@@ -158,6 +158,18 @@ class OracleFact:
         assert its >= 0
         return step[:n].copy(), its
 
+    def steihaug_rayleigh(self, n, hc, hr, hx, gradient, trust_radius, stat_tol=1e-6, max_iter=100):
+        """steihaug() plus the Rayleigh bounds steihaug_solver_rayleigh would report: (step, its, min, max)."""
+        hc, hr, hx, gradient = _i32(hc), _i32(hr), _f64(hx), _f64(gradient)
+        step = np.empty(max(n, 1))
+        lo, hi = C.c_double(), C.c_double()
+        fn = lib().oracle_steihaug_solve_rayleigh
+        fn.restype = C.c_int
+        its = fn(self._f, C.c_int(n), _p(hc), _p(hr), _p(hx), _p(gradient), C.c_double(trust_radius),
+                 C.c_double(stat_tol), C.c_int(max_iter), _p(step), C.byref(lo), C.byref(hi))
+        assert its >= 0
+        return step[:n].copy(), its, lo.value, hi.value
+
     def __del__(self):
         try:
             if self._f:

@@ -2239,6 +2239,12 @@ def test_gltr_device_phase_matches_host_loop(fact, kind):
     ref, _, _ = fact.tr_solve(H, g, big, method=1, stat_tol=1e-9, max_iter=400)
     nr = np.linalg.norm(ref)
     device_iterations = 0
+    import scipy.linalg as sla
+
+    Z = sla.null_space(J.toarray())
+    lam = np.linalg.eigvalsh(Z.T @ (Hs @ Z))
+    lam_lo, lam_hi = float(lam[0]), float(lam[-1])
+    ray = {}
     for radius, tol, cap in ((big, 1e-4, 400), (big, 1e-9, 400), (0.3 * nr, 1e-7, 400), (0.999 * nr, 1e-9, 400),
                              (big, 1e-30, 7), (big, 1e-30, 8), (big, 1e-30, 9), (big, 1e-30, 17), (big, 1e-30, 1), (big, 1e-30, 2)):
         out = {}
@@ -2246,7 +2252,14 @@ def test_gltr_device_phase_matches_host_loop(fact, kind):
             fact.set_option("lz_device_loop", dev)
             i0 = fact.info("lz_device_iterations")
             out[dev] = fact.tr_solve(H, g, radius, method=1, stat_tol=tol, max_iter=cap) + (fact.info("lz_device_iterations") - i0,)
+            ray[dev] = dict(fact.last_tr)
         (s0, d0, it0, _), (s1, d1, it1, dits) = out[0], out[1]
+        # the rayleigh slot (tr/tr_types.h:18-20): Rayleigh quotients of null-space directions - the same from the device
+        # phase's coefficients and the host loop's, inside the spectrum of the projected Hessian, never a time-out
+        for k_ in ("min_rayleigh", "max_rayleigh"):
+            assert abs(ray[0][k_] - ray[1][k_]) <= 1e-9 * max(1.0, abs(ray[0][k_])), (radius, tol, cap, ray)
+        assert lam_lo * (1 + 1e-9) - 1e-9 <= ray[1]["min_rayleigh"] <= ray[1]["max_rayleigh"] <= lam_hi * (1 + 1e-9) + 1e-9, (ray, lam_lo, lam_hi)
+        assert not ray[0]["timed_out"] and not ray[1]["timed_out"]
         assert it1 == it0 and 0 < it0 <= cap, (radius, tol, cap, it0, it1)
         assert rel_err(s1, s0) <= 1e-9, (radius, tol, cap)
         assert abs(d1 - d0) <= 1e-9 * max(1.0, abs(d0))
@@ -2268,6 +2281,22 @@ def test_gltr_device_phase_matches_host_loop(fact, kind):
         if dits >= 2:
             assert fact.info("lz_folded_products") > f0
     assert device_iterations > 0 and fact.info("lz_device_fallbacks") == 0
+    # time_limit (tr/tr_types.h:9-16) through the C ABI: a limit that is over at the first look ends both loops with the
+    # iterate reached (feasible, inside the region, fewer iterations than the cap), one of a minute changes nothing
+    for method in (0, 1):
+        for dev in (0, 1):
+            fact.set_option("lz_device_loop", dev)
+            fact.set_option("cg_device_loop", dev)
+            full, _, its_full = fact.tr_solve(H, g, big, method=method, stat_tol=1e-30, max_iter=60)
+            assert not fact.last_tr["timed_out"]
+            s_, _, its = fact.tr_solve(H, g, big, method=method, stat_tol=1e-30, max_iter=60, time_limit=1e-4)
+            assert fact.last_tr["timed_out"] and its < its_full, (method, dev, its, its_full)
+            assert np.all(np.isfinite(s_)) and np.linalg.norm(s_) <= big
+            assert np.abs(J @ s_).max() <= 1e-9 * max(1.0, np.abs(s_).max()) * abs(J).sum(axis=1).max()
+            s_, _, its = fact.tr_solve(H, g, big, method=method, stat_tol=1e-30, max_iter=60, time_limit=60.0)
+            assert not fact.last_tr["timed_out"] and its == its_full and np.array_equal(s_, full)
+    fact.set_option("lz_device_loop", 1)
+    fact.set_option("cg_device_loop", 1)
     H.free()
 
 

@@ -43,6 +43,7 @@ def test_shim_exports_reference_entry_points(shim):
                  "sleqp_hipfact_mat_create", "sleqp_hipfact_mat_set", "sleqp_hipfact_mat_mult_vec",
                  "sleqp_hipfact_mat_mult_vec_trans", "sleqp_hipfact_mat_release",
                  "sleqp_hipfact_tr_set_hessian", "sleqp_tr_solver_solve", "sleqp_tr_solver_release",
+                 "sleqp_tr_solver_set_time_limit", "sleqp_tr_solver_current_rayleigh",
                  "sleqp_fact_set_matrix", "sleqp_fact_solve", "sleqp_fact_solution", "sleqp_fact_cond",
                  "sleqp_fact_flags", "sleqp_fact_release"]:
         assert hasattr(shim, name), name
@@ -410,8 +411,8 @@ def test_tr_solver_shim_steihaug_against_oracle(shim, hipfact_lib, radius, matri
     g = np.random.default_rng(5).standard_normal(n)
     N, kc, kr, kd = oracle.fill_aug_jac(n, m, J.indptr, J.indices, J.data, vi, ci)
     stat_tol = 1e-6 if radius < 100 else 1e-4
-    want, _ = oracle.OracleFact(N, kc, kr, kd).steihaug(n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius,
-                                                        stat_tol=stat_tol)
+    want, _, want_lo, want_hi = oracle.OracleFact(N, kc, kr, kd).steihaug_rayleigh(
+        n, HL.indptr, HL.indices, HL.data, g, trust_radius=radius, stat_tol=stat_tol)
     settings, problem, iterate, aug, handle = _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver=1, stat_tol=stat_tol)
     calls = []
 
@@ -442,8 +443,14 @@ def test_tr_solver_shim_steihaug_against_oracle(shim, hipfact_lib, radius, matri
     assert rel_err(got, want) <= (1e-8 if radius < 100 else 1e-6)
     assert np.linalg.norm(got) <= radius * (1 + 1e-10)
     assert (len(calls) > 0) == matrix_free
+    # the rayleigh slot (tr/tr_types.h:18-20): the extremes of d.Bd / d.d the loop collected, against the oracle's
+    # restatement of steihaug_collect_rayleigh (same directions; the device sums its dot products in another order)
     lo, hi = C.c_double(), C.c_double()
     assert shim.sleqp_tr_solver_current_rayleigh(tr, C.byref(lo), C.byref(hi)) == 0
+    assert lo.value <= 1.0 <= hi.value
+    assert abs(lo.value - want_lo) <= 1e-10 * max(1.0, abs(want_lo)), (lo.value, want_lo)
+    assert abs(hi.value - want_hi) <= 1e-10 * max(1.0, abs(want_hi)), (hi.value, want_hi)
+    assert (want_lo, want_hi) != (1.0, 1.0)
     for v in (grad, mult, step):
         shim.sleqp_vec_free(C.byref(v))
     if H:
@@ -454,6 +461,86 @@ def test_tr_solver_shim_steihaug_against_oracle(shim, hipfact_lib, radius, matri
     shim.sleqp_iterate_release(C.byref(iterate))
     shim.sleqp_problem_release(C.byref(problem))
     shim.sleqp_settings_release(C.byref(settings))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tr_solver", [1, 3])  # SLEQP_TR_SOLVER_CG, _LSQR -> GLTR (everything but CG, newton.c:97-109)
+@pytest.mark.parametrize("matrix_free", [False, True])
+def test_tr_solver_shim_time_limit(shim, hipfact_lib, tr_solver, matrix_free):
+    """The `time_limit` argument of the solve slot (tr/tr_types.h:9-16, set through sleqp_tr_solver_set_time_limit,
+    tr/tr_solver.c:18-21): a solve that would run 100 iterations (a tolerance no iterate meets) under a limit of 1 ms
+    returns SLEQP_ABORT_TIME like steihaug_solver.c:297-310,490-492 / trlib_solver.c:631-644 - device-controlled loops
+    (explicit Hessian: the host looks every 8 iterations) and host loops (matrix-free) alike -, with a feasible step
+    inside the region; without the limit the same solver runs to its cap and returns SLEQP_OKAY (the reference's own
+    test of the mechanism: src/test/time_limit_test.c)."""
+    import time
+
+    import scipy.sparse as sp
+
+    from sleqp_amd import synth
+
+    n, m = 2000, 800
+    J = synth.uniform_jacobian(n, m, 4, 7)
+    vi, ci, W = synth.working_set_all_rows(n, m, 0.05, 7)
+    B = sp.random(n, n, density=0.002, random_state=3)
+    Hm = (B @ B.T + sp.diags(np.logspace(-3, 3, n))).tocsc()
+    HL = sp.tril(Hm, format="csc")
+    HL.sort_indices()
+    g = np.random.default_rng(5).standard_normal(n)
+    settings, problem, iterate, aug, handle = _tr_setup(shim, hipfact_lib, n, m, J, vi, ci, tr_solver=tr_solver,
+                                                        stat_tol=1e-28, max_iter=100)
+
+    def hess_prod(direction, duals, product, _):
+        d = np.ctypeslib.as_array(direction, shape=(n,))
+        np.ctypeslib.as_array(product, shape=(n,))[:] = Hm @ d
+        return 0
+
+    cb = HESS_CB(hess_prod)
+    shim.sleqp_problem_set_hess_prod_mini(problem, cb, None)
+    tr, ctl = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_hipfact_tr_solver_create(C.byref(tr), C.byref(ctl), problem, settings) == 0
+    assert shim.sleqp_hipfact_tr_bind(ctl, handle) == 0, shim.sleqp_error_msg()
+    H = None
+    if not matrix_free:
+        H = _push_matrix(shim, HL)
+        assert shim.sleqp_hipfact_tr_set_hessian(ctl, H) == 0, shim.sleqp_error_msg()
+    grad = _vec(shim, n, np.arange(n), g)
+    mult = _vec(shim, m, [], [])
+    step = C.POINTER(SleqpVecC)()
+    assert shim.sleqp_vec_create_empty(C.byref(step), n) == 0
+    dual = C.c_double()
+    radius = 1e6
+    # no limit (SLEQP_NONE, tr/tr_solver.c:47): runs to the iteration cap
+    t0 = time.perf_counter()
+    assert shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual)) == 0, \
+        shim.sleqp_error_msg()
+    t_full = time.perf_counter() - t0
+    full = _dense(step)
+    # 1 ms
+    shim.sleqp_tr_solver_set_time_limit.argtypes = [C.c_void_p, C.c_double]
+    assert shim.sleqp_tr_solver_set_time_limit(tr, C.c_double(1e-3)) == 0
+    t0 = time.perf_counter()
+    rc = shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual))
+    t_lim = time.perf_counter() - t0
+    assert rc == 1, (rc, shim.sleqp_error_msg())  # SLEQP_ABORT_TIME (pub_types.h:31)
+    got = _dense(step)
+    assert np.all(np.isfinite(got)) and np.linalg.norm(got) <= radius * (1 + 1e-10)
+    # feasible: in the null space of the working set (all rows of J, the active bounds' variables at zero)
+    assert np.abs(J @ got).max() <= 1e-8 * max(1.0, np.abs(got).max())
+    assert np.abs(got[vi >= 0]).max() <= 1e-8 * max(1.0, np.abs(got).max())
+    assert t_lim < t_full, (t_lim, t_full)
+    lo, hi = C.c_double(), C.c_double()
+    assert shim.sleqp_tr_solver_current_rayleigh(tr, C.byref(lo), C.byref(hi)) == 0 and lo.value <= hi.value
+    # a generous limit changes nothing
+    assert shim.sleqp_tr_solver_set_time_limit(tr, C.c_double(60.0)) == 0
+    assert shim.sleqp_tr_solver_solve(tr, aug, mult, grad, step, C.c_double(radius), C.byref(dual)) == 0
+    assert np.array_equal(_dense(step), full)
+    for v in (grad, mult, step):
+        shim.sleqp_vec_free(C.byref(v))
+    if H:
+        shim.sleqp_mat_release(C.byref(H))
+    assert shim.sleqp_tr_solver_release(C.byref(tr)) == 0 and not tr
+    _tr_teardown(shim, settings, problem, iterate, aug)
 
 
 @pytest.mark.gpu
