@@ -60,6 +60,17 @@ int hipfact_retain(hipfact_handle* handle);
  * hipfact_create when handle == NULL). */
 const char* hipfact_last_error(const hipfact_handle* handle);
 
+/* Warning of the last hipfact_set_matrix / hipfact_assemble_kkt that returned HIPFACT_OK, or NULL.  One exists today:
+ * the working set is rank deficient (a zero or wrongly signed pivot of A A^T) and K was factored with static pivoting -
+ * what MA57 reports as "Success - rank deficient", a positive status that the reference's MA57_CHECK_ERROR lets pass
+ * (fact/fact_ma57.c:41-42, 118-133).  Every pivot of A A^T is shifted by "static_pivot_delta" (1e-8; rows are
+ * equilibrated to unit norm) and the solves are refined against the caller's K until the backward error stalls: the
+ * null-space projection and min-norm solves (consistent right-hand sides, unique in x) come out as for the
+ * deduplicated working set; a right-hand side outside the range of K still ends in HIPFACT_ESINGULAR at the solve.
+ * Info keys: "num_perturbed" (pivots the unshifted attempt reported), "static_pivot_shift" (of the active
+ * factorisation, 0 = none), "static_pivot_runs".  Option "static_pivot" = 0 restores HIPFACT_ESINGULAR at once. */
+const char* hipfact_last_warning(const hipfact_handle* handle);
+
 /* ---- SleqpFact callbacks ------------------------------------------------ */
 
 /* Replaces SLEQP_FACT_SET_MATRIX (fact/fact_types.h:9-10; dispatched from

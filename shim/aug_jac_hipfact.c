@@ -112,6 +112,15 @@ aug_jac_set_iterate(SleqpIterate* iterate, void* data)
                                     NULL,
                                     NULL));
 
+  {
+    /* rank-deficient working set: factored with static pivoting (fact_ma57.c:41-42), and said */
+    const char* warning = hipfact_last_warning(jacobian->handle);
+    if (warning)
+    {
+      sleqp_log_warn("hipfact: %s", warning);
+    }
+  }
+
   HIPFACT_CALL(jacobian, hipfact_condition(jacobian->handle, &jacobian->condition));
 
   memcpy(jacobian->prev_var_index, jacobian->var_index, (size_t)num_variables * sizeof(int));

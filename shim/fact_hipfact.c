@@ -140,10 +140,10 @@ hipfact_log_events(HipFactData* data, const char* where)
                   hipfact_status,                                              \
                   hipfact_last_error((data)->handle),                          \
                   hipfact_status == HIPFACT_ESINGULAR                          \
-                    ? " - hipfact factors with a static pivot order and "      \
-                      "reports a rank-deficient working set where MA57 "       \
-                      "would delay pivots (pub_working_set.h:42-44 excludes "  \
-                      "such working sets)"                                     \
+                    ? " - K is singular and the right-hand side is not in "    \
+                      "its range (rank-deficient working sets as such are "   \
+                      "factored with static pivoting, like MA57's 'rank "      \
+                      "deficient' success, fact_ma57.c:41-42)"                 \
                     : "");                                                     \
     }                                                                          \
   } while (0)
@@ -168,6 +168,17 @@ hipfact_fact_set_matrix(void* fact_data, SleqpMat* matrix)
                                   sleqp_mat_cols(matrix),
                                   sleqp_mat_rows(matrix),
                                   sleqp_mat_data(matrix)));
+
+  /* a rank-deficient working set is factored with static pivoting, as MA57 factors it ("Success - rank deficient",
+   * fact_ma57.c:41-42: a positive status MA57_CHECK_ERROR lets pass, :118-133) - and said, which MA57's backend does
+   * not do */
+  {
+    const char* warning = hipfact_last_warning(data->handle);
+    if (warning)
+    {
+      sleqp_log_warn("hipfact: %s", warning);
+    }
+  }
 
   hipfact_log_events(data, "set_matrix");
 

@@ -25,7 +25,7 @@ ERRORS = {
 
 # every symbol include/hipfact.h declares
 SYMBOLS = [
-    "hipfact_create", "hipfact_free", "hipfact_retain", "hipfact_last_error", "hipfact_set_matrix", "hipfact_solve_sparse",
+    "hipfact_create", "hipfact_free", "hipfact_retain", "hipfact_last_error", "hipfact_last_warning", "hipfact_set_matrix", "hipfact_solve_sparse",
     "hipfact_solve_dense", "hipfact_solution", "hipfact_solution_view", "hipfact_condition", "hipfact_refactor_device",
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_check", "hipfact_stream",
     "hipfact_assemble_kkt", "hipfact_reduced_matrix", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
@@ -59,6 +59,8 @@ def load() -> C.CDLL:
     lib.hipfact_retain.argtypes = [vp]
     lib.hipfact_last_error.argtypes = [vp]
     lib.hipfact_last_error.restype = C.c_char_p
+    lib.hipfact_last_warning.argtypes = [vp]
+    lib.hipfact_last_warning.restype = C.c_char_p
     lib.hipfact_set_matrix.argtypes = [vp, ci, vp, vp, vp]
     lib.hipfact_solve_sparse.argtypes = [vp, ci, ci, vp, vp]
     lib.hipfact_solve_dense.argtypes = [vp, vp]

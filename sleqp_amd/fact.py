@@ -133,6 +133,11 @@ class HipFact:
         nnz = k_nnz.value
         return SleqpMat(N, N, kp, ki[:nnz].copy(), kx[:nnz].copy())
 
+    def last_warning(self):
+        """hipfact_last_warning: text, or None (rank-deficient working set factored with static pivoting)."""
+        w = self._lib.hipfact_last_warning(self._h)
+        return w.decode() if w else None
+
     def steihaug(self, hess: "SpMat", gradient, trust_radius: float, stat_tol: float = 1e-6, max_iter: int = 100):
         """Device-resident projected CG (tr/steihaug_solver.c:218-496): returns (step, tr_dual, iterations)."""
         g = np.ascontiguousarray(gradient, dtype=np.float64)
