@@ -34,6 +34,7 @@ struct RefineCtl {
   double omega_prev;
   double tol;         // effective tolerance of this solve
   double kappa;       // pivot-ratio condition estimate used for it
+  double rnorm, bnorm;  // ||r^||_inf, ||b^||_inf of the last residual (a statically pivoted factor is judged on r / b too)
 };
 struct DecideIn {
   RefineCtl* ctl;

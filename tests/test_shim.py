@@ -263,6 +263,45 @@ def test_fact_shim_changing_working_sets_cost_one_analysis(shim, hipfact_lib):
 
 
 @pytest.mark.gpu
+def test_fact_shim_rank_deficient_working_set_warns_like_ma57(shim, hipfact_lib):
+    """A K whose working set holds a duplicated row: MA57's backend factors it ("Success - rank deficient",
+    fact_ma57.c:41-42: a positive status MA57_CHECK_ERROR lets pass, :118-133) and the SQP run goes on.  Through the C
+    shim: sleqp_fact_set_matrix returns SLEQP_OKAY, a warning goes through sleqp_log_warn (pub_log.h), and the
+    projection (standard_aug_jac.c:396-435) equals the oracle's on the deduplicated working set."""
+    import scipy.sparse as sp
+
+    import oracle
+    from sleqp_amd import synth
+
+    n, m = 300, 120
+    J0 = synth.banded_jacobian(n, m, 8, 60, 5).tocsr()
+    J = sp.vstack([J0, J0[33]]).tocsc()
+    J.sort_indices()
+    vi = np.full(n, -1, dtype=np.int32)
+    ci = np.arange(m + 1, dtype=np.int32)
+    ci_d = ci.copy()
+    ci_d[m] = -1
+    N, kc, kr, kd = oracle.fill_aug_jac(n, m + 1, J.indptr, J.indices, J.data, vi, ci)
+    Nd, kcd, krd, kdd = oracle.fill_aug_jac(n, m + 1, J.indptr, J.indices, J.data, vi, ci_d)
+    shim.sleqp_mini_log_drain.restype = C.c_char_p
+    shim.sleqp_mini_log_drain()
+    settings, fact = C.c_void_p(), C.c_void_p()
+    assert shim.sleqp_settings_create(C.byref(settings)) == 0
+    assert shim.sleqp_fact_create_default(C.byref(fact), settings) == 0, shim.sleqp_error_msg()
+    K = _push_lower(shim, N, kc, kr, kd)
+    assert shim.sleqp_fact_set_matrix(fact, K) == 0, shim.sleqp_error_msg()
+    log = shim.sleqp_mini_log_drain().decode()
+    assert "rank deficient" in log and "static pivoting" in log, log
+    g = np.random.default_rng(3).standard_normal(n)
+    got = _fact_solve(shim, fact, np.concatenate([g, np.zeros(N - n)]), 0, n)
+    idx, val = oracle.OracleFact(Nd, kcd, krd, kdd).project_nullspace(n, np.arange(n), g)
+    assert rel_err(got, oracle.vec_to_raw(n, idx, val)) <= 1e-8
+    shim.sleqp_mat_release(C.byref(K))
+    assert shim.sleqp_fact_release(C.byref(fact)) == 0
+    shim.sleqp_settings_release(C.byref(settings))
+
+
+@pytest.mark.gpu
 def test_psd_fact_shim_behind_the_reduced_aug_jac(shim, hipfact_lib):
     """sleqp_fact_hipfact_psd_create declares PSD | LOWER (pattern fact_cholmod.c:231-262): create_aug_jac
     (trial_point.c:94-101) then puts the reduced AugJac in front of it, whose matrix is the lower triangle of
