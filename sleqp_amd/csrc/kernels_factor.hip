@@ -22,7 +22,6 @@
 //   kernels_front_pivot.inc   pivot block of a front: blocked LDL^T as free-running waves, posted tiles
 //   kernels_front_update.inc  panel solve, Schur tiles, the per-level kernels
 //   kernels_front_fused.inc   panel solve + Schur tile of a front as one role of the dataflow launch
-//   kernels_front_whole.inc   a whole front in one workgroup (the wide bottom levels of the dataflow launch)
 //   kernels_solve_level.inc   level-scheduled / one-launch-per-direction solves (fallback)
 //   kernels_factor_top.inc    k_factor_top: the upper levels of the factorisation as one dataflow launch
 //   kernels_solve_wide.inc    wide fronts of the fallback solves
@@ -41,9 +40,6 @@ namespace hipfact {
 #include "kernels_front_pivot.inc"
 #include "kernels_front_update.inc"
 #include "kernels_front_fused.inc"
-#ifdef HIPFACT_WHOLE_ROLE  // (an experiment that is compiled on request only: its 17 accumulator tiles per wave push the whole
-#include "kernels_front_whole.inc"  // dataflow kernel to 256 registers and every role of it got ~3 % slower)
-#endif
 #include "kernels_solve_panels.inc"
 #include "kernels_factor_top.inc"
 }  // namespace hipfact
