@@ -48,7 +48,7 @@ namespace hipfact {
 namespace hipfact {
 #define INST_MVALS(IDX, PK)                                                                                          \
   template __global__ void k_mvals_prod<IDX, PK>(long long, const IDX*, const int*, const int*, const IDX*, const double*, \
-                                                double*, long long, int, const int*, double*, int, const LongProd*,   \
+                                                double*, int, const LongProd*,                                       \
                                                 double*, unsigned int*);
 INST_MVALS(unsigned int, true)
 INST_MVALS(unsigned int, false)
@@ -57,9 +57,9 @@ INST_MVALS(long long, false)
 #undef INST_MVALS
 #define INST_FRONT(CH)                                                                                              \
   template __global__ void k_front_pivot<CH>(const FrontItem*, double*, double*, int*, const int*, const int*,     \
-                                             const PullDesc*, int, const unsigned*);                                \
+                                             const PullDesc*, int);                                                 \
   template __global__ void k_front_panel<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
-                                             const PullDesc*, int, const unsigned*);                                \
+                                             const PullDesc*, int);                                                 \
   template __global__ void k_front_schur<CH>(const FrontItem*, double*, double*, const int*, const int*,           \
                                              const PullDesc*, int);
 INST_FRONT(true)

@@ -280,14 +280,26 @@ def test_error_behaviour(fact):
     with pytest.raises(HipfactError) as e:
         fact.solve(np.zeros(0))
     assert e.value.code == -5
-    # rank-deficient working set (duplicate rows): zero pivot -> HIPFACT_ESINGULAR,
-    # like "Failed to factorize using LAPACK" (fact_lapack.c:117-120)
+    # rank-deficient working set (duplicate rows): the LAPACK-restating oracle fails ("Failed to factorize using
+    # LAPACK", fact_lapack.c:117-120); MA57 - the parity target - factors such a K ("Success - rank deficient",
+    # fact_ma57.c:41-42) and so does the device, by static pivoting, with a warning; a right-hand side outside the
+    # range of K is reported at the solve, one inside it is solved; static_pivot = 0: HIPFACT_ESINGULAR at once
     N, kc, kr, kd = oracle.fill_aug_jac(2, 2, [0, 2, 4], [0, 1, 0, 1], [1.0, 1.0, 2.0, 2.0], [-1, -1], [0, 1])
+    with pytest.raises(ZeroDivisionError):
+        oracle.OracleFact(N, kc, kr, kd)
+    fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert fact.info("num_perturbed") >= 1 and "rank deficient" in fact.last_warning()
+    with pytest.raises(HipfactError) as e:
+        fact.solve(np.array([0.0, 0.0, 1.0, 0.0]))  # x0 + 2 x1 = 1 and = 0
+        fact.solution_raw(0, N)
+    assert e.value.code == -3
+    fact.solve(np.array([0.0, 0.0, 5.0, 5.0]))  # consistent: min-norm x = (1, 2)
+    assert rel_err(fact.solution_raw(0, 2), np.array([1.0, 2.0])) <= 1e-8
+    fact.set_option("static_pivot", 0)
     with pytest.raises(HipfactError) as e:
         fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
     assert e.value.code == -3
-    with pytest.raises(ZeroDivisionError):
-        oracle.OracleFact(N, kc, kr, kd)
+    fact.set_option("static_pivot", 1)
     # malformed matrix
     with pytest.raises(HipfactError) as e:
         fact.set_matrix(SleqpMat(2, 2, [0, 1, 3], [0, 0, 1], [1.0, 1.0, 1.0]))
@@ -1095,38 +1107,6 @@ def test_determinism(fact):
         fact.solve(b)
         outs.append(fact.solution_raw(0, N))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
-
-
-def test_assign_mode_panels_give_the_same_bits(fact):
-    """`assign_panels`: no zero fill of the factor arena - the kernels that enter a front read its panel through a bit
-    mask of M's entries and ignore what the previous factorisation left there.  Same values in the same order: the
-    solution must be bit for bit the one of the cleared arena, also on the second and third factorisation (when the
-    arena holds the previous factor) and with other values."""
-    from bench import make_problem
-    from sleqp_amd.sparse import SleqpMat
-
-    J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", 0)
-    vx2 = np.array(vx, copy=True)
-    n = J.shape[1]
-    rng = np.random.default_rng(21)
-    off = np.ones(len(vx2), dtype=bool)
-    off[np.asarray(cp[:n])] = False  # (the unit diagonal stays)
-    vx2[off] *= 1.0 + 0.3 * rng.standard_normal(int(off.sum()))
-    outs = {}
-    for mode in (0, 1):
-        fact.set_option("assign_panels", mode)
-        got = []
-        for vals in (vx, vx2, vx):
-            fact.set_matrix(SleqpMat(N, N, cp, ri, vals))
-            if mode == 1:
-                assert fact.info("assign_panels") == 1  # (every level of this tree pulls its children)
-            fact.solve(b)
-            got.append(fact.solution_raw(0, N))
-        outs[mode] = got
-    for a, c in zip(outs[0], outs[1]):
-        assert np.array_equal(a, c)
-    assert not np.array_equal(outs[0][0], outs[0][1])
-    fact.set_option("assign_panels", 0)
 
 
 @pytest.mark.parametrize("kind,n,m", [("b", 6000, 3000), ("u", 1500, 700)])
