@@ -290,41 +290,129 @@ int hipfact_tridiag_tr(int k, const double* delta, const double* gamma, double g
 
 /* ---- options / introspection ------------------------------------------- */
 
-/* Options.
- *   numerics:  "refine_steps" (correction passes carried by every solve graph,
- *              default 1, 0 = plain solve without residual; the passes return at
- *              once when the device-side control block reports convergence),
- *              "refine_max" (total passes including those continued by
- *              hipfact_solution / hipfact_check, default 10), "refine_tol"
- *              (forward-error target, default 1e-10: the backward-error
- *              tolerance is refine_tol / condition estimate, clamped to
- *              [4.5e-16, 1e-12]), "refine_adaptive" (0: every in-graph pass
- *              runs), "fail_omega" (a solve that stalls above this backward
- *              error is reported as singular, default 1e-8), "equilibrate"
- *              (row equilibration of the constraint block, default 1);
- *   analysis (take effect at the next set_matrix / assemble, which re-analyses):
- *              "ordering" (0 nested dissection, 1 AMD, 2 natural), "wmax"
- *              (widest supernode, default 128), "max_children" (amalgamation
- *              keeps fronts at this many children, default 4), "nd_leaf",
- *              "nd_sep_frac", "force_generic";
- *   schedule (results are bit-identical for every setting; the parity tests
- *   sweep them):
- *              "use_graph" (replay the launch sequence as a hipGraph),
- *              "factor_top_max" (levels with at most this many fronts are
- *              factored inside the single dataflow launch, 0 = off),
- *              "top_max_fronts" (same for the two solve launches),
- *              "wide_min_rows" (fronts with at least this many update rows
- *              are solved by several workgroups, 0 = off),
- *              "pull_max_children" (0 = extend-add through the separate
- *              assembly kernel), "top_prefetch", "split_max_fronts",
- *              "solve_fused" (0: the per-level / two-launch solve kernels on
- *              the factor panels instead of the single launch on solve
- *              panels), "spanel_fold" (0: the solve panels are built by a
- *              launch of their own instead of by filler workgroups of the
- *              dataflow launch; "spanel_fold_room": how many per level);
- *   "profile" (1: event-time every kernel class, read back with
- *              "prof_<class>_ms" / "prof_<class>_count"; -1 resets).
- * Unknown names return HIPFACT_EINVAL. */
+/* Options of hipfact_set_option.  Schedule options give bit-identical results for every setting unless their line
+ * says otherwise (the parity tests sweep them); analysis options take effect at the next set_matrix / assemble, which
+ * re-analyses.  The table is generated from the source: */
+/* BEGIN OPTION TABLE (generated by scripts/gen_option_table.py from sleqp_amd/csrc/abi_options.inc)
+ * 50 options; unknown names return HIPFACT_EINVAL.
+ *   "refine_steps"
+ *       correction passes carried by every solve graph (default 1; 0: plain solve, no residual); they
+ *       return at once when the device-side control block reports convergence
+ *   "refine_max"
+ *       total correction passes of a solve, including those continued by hipfact_solution /
+ *       hipfact_check (default 10)
+ *   "refine_adaptive"
+ *       0: every in-graph correction pass runs unconditionally
+ *   "refine_tol"
+ *       forward-error target (default 1e-10): the backward-error tolerance is refine_tol / condition
+ *       estimate, clamped to [4.5e-16, 1e-12]
+ *   "fail_omega"
+ *       a solve whose refinement stalls above this backward error is reported as singular (default 1e-8)
+ *   "static_pivot"
+ *       0: a zero / wrongly signed pivot is HIPFACT_ESINGULAR at once (rounds 1 - 5)
+ *   "static_pivot_delta"
+ *       the shift of every pivot of A A^T when a rank-deficient working set is factored with static
+ *       pivoting (default 1e-8; rows are equilibrated to unit norm)
+ *   "equilibrate"
+ *       takes effect at the next factorisation
+ *   "use_graph"
+ *       0: enqueue the launch sequences instead of replaying captured hipGraphs
+ *   "top_max_fronts"
+ *       0 disables the single-launch top-of-tree solve
+ *   "factor_top_max"
+ *       0: one launch per phase and level everywhere
+ *   "wide_min_rows"
+ *       fronts with at least this many update rows are solved by several workgroups in the per-level
+ *       solve kernels (default 256; 0: off)
+ *   "top_prefetch"
+ *       0: the two-launch solve kernels fetch their panels behind the dependency wait (tests)
+ *   "pull_max_children"
+ *       0: extend-add always through the separate assembly kernel
+ *   "debug_fake_timeout"
+ *       test hook for the fallback to the per-level launches
+ *   "factor_top_levels"
+ *       at most this many levels in the single-launch top-of-tree factorisation (tests)
+ *   "solve_slices"
+ *       0: one item per front in the fused solve launch (fronts of up to 1024 rows only)
+ *   "chain_pairs"
+ *       dense chains: two fronts per trailing update (0: one Schur update per front)
+ *   "solve_sorted"
+ *       solve items of a level: biggest fronts first (0: plan order)
+ *   "solve_whole_max"
+ *       a front stays ONE solve item up to this many panel entries per thread
+ *   "xupd_blocks"
+ *       workgroups of the x update inside the tree launch
+ *   "chain_fuse"
+ *       0: single-front levels of a dense chain run pivot block and panel as two launches instead of one
+ *       small dataflow launch
+ *   "cg_residual_update"
+ *       0: the projected CG keeps r as the reference's loop does
+ *   "cg_device_loop"
+ *       0: the host reads the dot products of every CG iteration (steihaug_impl)
+ *   "lz_device_loop"
+ *       0: GLTR with the host in every iteration (gltr_impl)
+ *   "xupd_fused"
+ *       0: x = b_x - A^T y as a launch of its own behind the tree (k_x_saddle)
+ *   "refine_check_backoff"
+ *       the interval between residual checks is multiplied by this after every check that passes
+ *       (default 2; 1: fixed interval), up to 64 solves
+ *   "refine_check_every"
+ *       residual check on every k-th solve of a well-conditioned factorisation
+ *   "decide_lazy"
+ *       0: every solve graph ends with its own verdict launch
+ *   "rhs_fused"
+ *       0: k_rhs_saddle in front of the single-launch solve
+ *   "spanel_fold"
+ *       0: the solve panels in a launch of their own behind the factorisation
+ *   "spanel_fold_room"
+ *       solve-panel items dealt in beside a level's own pivot and panel items of the dataflow launch:
+ *       workgroup slots per level (default 224)
+ *   "factor_hint_peek"
+ *       0: a refactorisation does not look at the last delivered refinement verdict (every first solve
+ *       graph carries a correction pass)
+ *   "top_block_breakeven"
+ *       solves of one factorisation from which forming the dense top block of the solve tree pays
+ *       (default 48)
+ *   "solve_fused"
+ *       0: the two-launch / per-level solve kernels on the factor panels
+ *   "top_block_after"
+ *       the top levels of the solve tree as one dense block from this solve of a factorisation on (0:
+ *       never)
+ *   "boundary_fast"
+ *       0: host vectors through pageable borrows and three blocking points (round 3)
+ *   "validate_rhs"
+ *       walk the index array of every sparse right-hand side on the host (debug)
+ *   "boundary_profile"
+ *       where solve + solution spend their time (info keys bd_*); resets the sums
+ *   "superset_vtable"
+ *       0: no reuse across working sets (every changed pattern is analysed on its own rows; active
+ *       bounds are still eliminated - exact_pattern = 1 for K as it is)
+ *   "spmv_stream"
+ *       0: every sparse product through the lanes-per-row kernel (default: matrices from spmv_stream_min
+ *       entries on are streamed in row blocks)
+ *   "spmv_stream_min"
+ *       entries from which a sparse product is streamed (default 4 M: below, the matrix lives in the
+ *       Infinity Cache)
+ *   "exact_pattern"
+ *       1: K is analysed exactly as given - no row dictionary, unit rows of active bounds stay in the
+ *       structure (what hipfact_reduced_matrix needs)
+ *   "assemble_superset"
+ *       0: hipfact_assemble_kkt analyses every working set on its own rows (no superset plan)
+ *   "plan_cache"
+ *       inactive plan states kept (LRU); 0: one pattern at a time
+ *   "profile"
+ *       event-time every kernel class; value < 0 resets the counters
+ *   "ordering"
+ *       0 nested dissection + AMD leaves (default), 1 AMD on the whole graph, 2 natural
+ *   "max_children"
+ *       relaxed amalgamation keeps fronts at this many children (default 4 = what the pull extend-add
+ *       takes in one block)
+ *   "force_generic"
+ *       1: no saddle-point structure detection, static 1 x 1 pivots on K as given (symmetric positive
+ *       definite input: the PSD shim)
+ *   "dense_mode"
+ *       1: late elimination inside the tree (default), 2: low-rank correction, 0: off
+ * END OPTION TABLE */
 int hipfact_set_option(hipfact_handle* h, const char* name, double value);
 
 /* Info (of the last finished solve: "last_omega" backward error in the

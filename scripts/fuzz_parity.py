@@ -94,7 +94,7 @@ def one_case(fact, rng, idx, tol=None, krylov_checks=("gltr", "cg")):
     if not np.isfinite(cond_proxy) or cond_proxy > 1e10:
         return tag, "skipped (ill conditioned)"
     fact.set_option("dense_mode", mode)
-    for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # e.g. FUZZ_OPTS=xupd_fused=0,top_block_single=0
+    for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # e.g. FUZZ_OPTS=xupd_fused=0,rhs_fused=0
         fact.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     aug = StandardAugJac(n, fact)
     aug.set_iterate(SleqpMat.from_scipy(J), vi, ci)

@@ -83,7 +83,6 @@ def run():
         f.set_option("use_graph", 0)
         f.set_option("refine_steps", 0)
         f.set_option("top_block_after", after)
-        f.set_option("top_block_max", cap)
         f.set_matrix(SleqpMat(N, N, cp, ri, vx))
         for _ in range(5):
             f.solve(b)
@@ -98,7 +97,7 @@ def run():
         base = t[ntr:ntr + nfb, 0].min()  # (first forward item of this launch; slots of other blocks may hold older stamps)
         t = (t - base) / 100.0
         fw = t[ntr:ntr + nfb]
-        single = nT > 0 and bool(f.info("top_block_single"))
+        single = nT > 0
         ntb = 0 if single else ntf
         tf = t[ntr + nfb:ntr + nfb + ntf]
         bw = t[ntr + nfb + ntf + ntb:ntr + 2 * nfb + ntf + ntb]

@@ -13,7 +13,7 @@ db = torch.from_numpy(b).cuda()
 ref = None
 for after, cap, single in ((0, 2048, 0), (2, 2048, 0), (2, 2048, 1), (2, 1024, 1)):
     f = HipFact(device=0)
-    f.set_option("top_block_after", after); f.set_option("top_block_max", cap); f.set_option("top_block_single", single)
+    f.set_option("top_block_after", after)
     f.set_matrix(SleqpMat(N, N, cp, ri, vx))
     z = torch.empty_like(db)
     for _ in range(4):

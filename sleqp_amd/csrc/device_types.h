@@ -179,18 +179,16 @@ constexpr int SPMV_NNZ = 2048;  // k_spmv_stream: entries per row block / workgr
 constexpr int SPMV_T = 256;
 constexpr int TREE_LDS = 2 * 1024 + 8;  // k_solve_tree without a top block (dynamic LDS, doubles)
 struct TopBlockIn {
-  int nT, ntf, ntb;
-  const TopBlockItem* __restrict__ items;  // ntf forward items, then ntb backward items
-  const double* __restrict__ XTf;
-  const double* __restrict__ XTb;
+  int nT, ntf;
+  const TopBlockItem* __restrict__ items;  // ntf items
+  const double* __restrict__ XTf;          // their thread-major rows of Z = X_T^T D_T^-1 X_T (= inv(S_T)): ONE product y_T = Z f_T
   const int* __restrict__ tpos;       // T-local index -> pivot position
   const int* __restrict__ gptr;       // nT + 1: sources of f_T[i] among the update vectors of the fronts below T ...
   const long long* __restrict__ gsrc; // ... as offsets into uvec (added in this fixed order)
   double* __restrict__ xhatT2;        // 2 x nT exchange slots (by launch parity), sentinel between uses
   double* __restrict__ tT2;           // the same for the rows of the right-hand side t that belong to T ...
   int ntr;                            // ... formed by the FIRST ntr workgroups of the launch (64 rows each; 0: t is in y)
-  int single;                         // 1: ONE product y_T = Z f_T with Z = X_T^T D_T^-1 X_T (= inv(S_T)); XTf holds the rows of Z, ntb = 0
-  // single product: how many items of THIS launch have gathered f_T (two counters, by launch parity; item 0 clears
+  // how many items of THIS launch have gathered f_T (two counters, by launch parity; item 0 clears
   // the other one).  Every item reads every update vector that reaches T, and a front below T turns around as soon as
   // the rows of y_T it needs are posted - by ONE item, while another may not have gathered yet: the backward items
   // put their update slots back to the sentinel only once all ntf items have read them.

@@ -80,19 +80,6 @@ struct XupdIn {
   int acc;
   int nblocks;
   double* __restrict__ dot_out;  // per workgroup: partial of b_x . z_x (the r.g of a CG iteration), or null
-  // A symmetric product H z_x behind the x update, inside the same launch (the Lanczos loop of krylov_device.inc): hn
-  // more workgroups follow the x-update ones, poll the entries of z_x they need (the caller left the sentinel in
-  // z_x[0 .. n), the x update posts its entries with device scope) and leave H z_x and the block partials of
-  // z_x . H z_x.  hn == 0: no product.  Lower triangle by rows (hp, hi, hv) and by columns (hp2, hi2, hv2).
-  int hn;
-  const int* __restrict__ hp;
-  const int* __restrict__ hi;
-  const double* __restrict__ hv;
-  const int* __restrict__ hp2;
-  const int* __restrict__ hi2;
-  const double* __restrict__ hv2;
-  double* __restrict__ hz;
-  double* __restrict__ hpart;
 };
 struct CgCtl {
   double rg, z_nrm_sq, rel_tol_sq, rad_sq, alpha, beta, tau;

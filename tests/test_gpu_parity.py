@@ -1606,42 +1606,6 @@ def test_dense_chain_levels_as_small_dataflow_launches(fact):
     fact.set_option("factor_top_levels", 1 << 20)
 
 
-def test_dense_chain_lookahead_gives_the_same_factor(fact):
-    """`chain_lookahead` (off by default): the trailing update of a pair of chain fronts as two
-    launches on a CU-masked stream of its own, the next pair's pivot blocks and panels beside it on a second one, events
-    in between, no graph.  Same tiles, same arithmetic: the solutions are the bits of the serial schedule, over
-    repeated factorisations (the events and the posted slots are reused), and the option goes back to the graph."""
-    from sleqp_amd.sparse import SleqpMat
-
-    J = synth.uniform_jacobian(10000, 5000, 10, 0)  # BASELINE configs[2]: a 4264-wide dense chain, 17 pairs
-    N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
-    K = synth.kkt_full_matrix(N, kc, kr, kd)
-    rng = np.random.default_rng(11)
-    rhs = [rng.standard_normal(N) for _ in range(2)]
-    outs = {}
-    fact.set_option("refine_steps", 0)
-    for la in (0, 1, 0):
-        fact.set_option("chain_lookahead", la)
-        runs0 = fact.info("chain_lookahead_runs")
-        res = []
-        for rep in range(3):
-            fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
-            for b in rhs:
-                fact.solve(b)
-                res.append(fact.solution_raw(0, N))
-            assert fact.info("solve_timeouts") == 0 and fact.info("dataflow_fallbacks") == 0
-        assert (fact.info("chain_lookahead_runs") - runs0 >= 3) == bool(la)
-        outs.setdefault(la, res)
-        for a_, b_ in zip(outs[la], res):
-            assert np.array_equal(a_, b_)
-    for a_, b_ in zip(outs[1], outs[0]):
-        assert np.array_equal(a_, b_)
-    assert np.array_equal(outs[1][0], outs[1][4])
-    assert scaled_residual(K, outs[1][0], rhs[0]) <= 1e-8
-    fact.set_option("chain_lookahead", 0)
-    fact.set_option("refine_steps", 1)
-
-
 def test_device_resident_loop_of_one_solve_per_factorisation():
     """A loop `refactor_device; solve_device` with no synchronising entry point in between (bench.py's unit) never
     reaches the second-solve peek that drops the correction pass from the solve graphs; the refactorisation looks at
@@ -2344,14 +2308,6 @@ def test_gltr_device_phase_matches_host_loop(fact, kind):
         if kind == "positive_definite" and radius == big and cap >= 2:
             assert dits == it1  # (never left: every iteration on the device)
         device_iterations += dits
-        # option: the product H y_{k+1} inside the projection's launch (workgroups behind the x update that poll y)
-        fact.set_option("lz_fold_product", 1)
-        f0 = fact.info("lz_folded_products")
-        s2, d2, it2 = fact.tr_solve(H, g, radius, method=1, stat_tol=tol, max_iter=cap)
-        fact.set_option("lz_fold_product", 0)
-        assert it2 == it0 and rel_err(s2, s0) <= 1e-9 and abs(d2 - d0) <= 1e-9 * max(1.0, abs(d0))
-        if dits >= 2:
-            assert fact.info("lz_folded_products") > f0
     assert device_iterations > 0 and fact.info("lz_device_fallbacks") == 0
     # time_limit (tr/tr_types.h:9-16) through the C ABI: a limit that is over at the first look ends both loops with the
     # iterate reached (feasible, inside the region, fewer iterations than the cap), one of a minute changes nothing
