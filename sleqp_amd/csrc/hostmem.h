@@ -9,6 +9,7 @@
 #include <sys/mman.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <new>
 #include <utility>
 #include <vector>
@@ -46,7 +47,8 @@ template <class V>
 inline void huge_advise(V& v) {
   using T = typename V::value_type;
   const size_t bytes = v.capacity() * sizeof(T);
-  if (bytes < ((size_t)4 << 20)) return;
+  static const bool off = getenv("HIPFACT_NO_THP") != nullptr;
+  if (off || bytes < ((size_t)4 << 20)) return;
   const uintptr_t lo = ((uintptr_t)v.data() + 4095) & ~(uintptr_t)4095;
   const uintptr_t hi = ((uintptr_t)v.data() + bytes) & ~(uintptr_t)4095;
   if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);  // advisory: failure leaves ordinary pages

@@ -2357,8 +2357,7 @@ def test_host_boundary_fast_path(fact):
     lib = _lib.load()
     for _ in range(2):  # (steady state of the factorisation: the top levels of the solve tree as one dense block)
         fact.solve(np.ones(N))
-    variants = [dict(boundary_fast=1, boundary_h2d=0, boundary_d2h=0), dict(boundary_fast=1, boundary_h2d=1, boundary_d2h=1),
-                dict(boundary_fast=1, boundary_h2d=0, boundary_d2h=0, validate_rhs=1), dict(boundary_fast=0)]
+    variants = [dict(boundary_fast=1), dict(boundary_fast=1, validate_rhs=1), dict(boundary_fast=0)]
     for name, ix, vals in cases:
         ref.solve_sparse(ix, vals)
         want = ref.raw_solution()
