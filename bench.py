@@ -582,6 +582,13 @@ def structural_robustness_bench(J4, local_rank):
         rg["factor_plus_solve_vs_base"] = rg["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
         rg["unit_per_gflop_vs_base"] = (rg["factor_plus_solve_ms"] / max(rg["flops"], 1.0)) / (base["factor_plus_solve_ms"] / max(base["flops"], 1.0))
         out["grid2d_g224"] = rg
+        # ... and in three dimensions (missing 3): planes of ~2 g^2 cells as separators, 70 tree levels,
+        # 6e10 flops for a system of config 4's size - every level of a chain of <= 128-column fronts costs its latency
+        r3 = device_unit(synth.grid3d_jacobian(37, 0), local_rank, reps=4, solves=8)
+        r3["factor_plus_solve_vs_base"] = r3["factor_plus_solve_ms"] / base["factor_plus_solve_ms"]
+        r3["unit_per_gflop_vs_base"] = (r3["factor_plus_solve_ms"] / max(r3["flops"], 1.0)) / (base["factor_plus_solve_ms"] / max(base["flops"], 1.0))
+        r3["factor_TFLOPs"] = r3["flops"] / max(r3["factor_ms"], 1e-9) / 1e9
+        out["grid3d_g37"] = r3
         J2 = synth.banded_jacobian(20000, 10000, 20, 200, 0)
         b2 = device_unit(J2, local_rank)
         out["n2e4_base"] = b2

@@ -55,6 +55,30 @@ def grid2d_jacobian(g: int, seed: int = 0) -> sp.csc_matrix:
     return J
 
 
+def grid3d_jacobian(g: int, seed: int = 0) -> sp.csc_matrix:
+    """PDE-constrained 3-D family (missing 3): a g x g x g grid of states and as many controls, one
+    constraint per cell - the 7-point Laplacian of the states plus the cell's control.  n = 2 g^3, m = g^3 (g = 37:
+    n = 101 306, m = 50 653, the size of BASELINE's config 4); ``J J^T`` is a 25-point stencil, the separators of a nested
+    dissection are planes of ~2 g^2 cells: thousands of columns, chains of dozens of 128-column fronts."""
+    rng = np.random.default_rng(seed)
+    cell = np.arange(g * g * g, dtype=np.int64).reshape(g, g, g)
+    rows, cols, vals = [], [], []
+    for d, base in (((0, 0, 0), 6.0), ((1, 0, 0), -1.0), ((-1, 0, 0), -1.0), ((0, 1, 0), -1.0), ((0, -1, 0), -1.0),
+                    ((0, 0, 1), -1.0), ((0, 0, -1), -1.0)):
+        sl_src = tuple(slice(max(0, -k), g - max(0, k)) for k in d)
+        sl_dst = tuple(slice(max(0, k), g - max(0, -k)) for k in d)
+        src, dst = cell[sl_src].ravel(), cell[sl_dst].ravel()
+        rows.append(src)
+        cols.append(dst)
+        vals.append(base * (1.0 + 0.1 * rng.random(src.size)))
+    rows.append(cell.ravel())  # the cell's control
+    cols.append(g ** 3 + cell.ravel())
+    vals.append(1.0 + 0.1 * rng.random(g ** 3))
+    J = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(g ** 3, 2 * g ** 3))
+    J.sort_indices()
+    return J
+
+
 def uniform_jacobian(n: int, m: int, nz_per_row: int = 10, seed: int = 0) -> sp.csc_matrix:
     """Config 3 family: ``nz_per_row`` entries per row at uniform random distinct columns."""
     rng = np.random.default_rng(seed)

@@ -2044,6 +2044,34 @@ def test_wide_separators_of_a_2d_grid(fact):
         assert fact.info("dataflow_fallbacks") == 0
 
 
+def test_plane_separators_of_a_3d_grid(fact):
+    """VERDICT round 5, missing 3: a PDE-constrained 3-D grid (7-point Laplacian states + controls).  J J^T is a 25-point
+    stencil and the separators of the dissection are planes of ~2 g^2 cells - chains of many 128-column fronts with
+    thousands of update rows (dense-chain machinery: paired trailing updates, row-sliced solve items): against the
+    oracle's sparse LDL^T and the residual; the projection lands in the null space of the constraint rows."""
+    from sleqp_amd.sparse import SleqpMat, SleqpVec
+
+    for g in (12, 20):
+        J = synth.grid3d_jacobian(g, 1)
+        m, n = J.shape
+        N, kc, kr, kd = synth.kkt_lower_from_jacobian(J)
+        K = synth.kkt_full_matrix(N, kc, kr, kd)
+        fact.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        assert fact.info("max_w") <= 128 and fact.info("nlevels") >= 8
+        b = np.random.default_rng(g).standard_normal(N)
+        fact.solve(b)
+        z = fact.solution_raw(0, N)
+        assert scaled_residual(K, z, b) <= RESID_TOL
+        assert rel_err(z, oracle.OracleLdl(N, kc, kr, kd).solve(b)) <= 1e-8
+        gvec = np.zeros(N)
+        gvec[:n] = np.random.default_rng(3).standard_normal(n)
+        fact.solve(SleqpVec.from_raw(gvec))
+        Pg = fact.solution_raw(0, n)
+        A = J.tocsr()
+        assert np.abs(A @ Pg).max() <= 1e-9 * np.abs(A).sum(axis=1).max() * np.abs(gvec).max()
+        assert fact.info("dataflow_fallbacks") == 0
+
+
 def test_full_size_krylov_loops(fact):
     """BASELINE.json configs[3] (n = 1e5, m = 5e4) under the device-resident Krylov loops of the EQP step, with the
     banded Hessian of the bench: the device-controlled CG against the host-driven loop (iteration count, step), the
@@ -2579,3 +2607,44 @@ def test_concurrent_instances_like_thread_test():
     for r in results:
         assert not isinstance(r, Exception), r
         assert r <= REL_TOL
+
+
+def test_two_full_size_handles_share_one_gpu():
+    """Two handles with BASELINE's config 4 each, driven from two threads on one GPU (what `bench.py --gpus 2` does on a
+    box with one device, and what two SLEQP instances of thread_test.c:77-110 would do): the dataflow launches of one
+    handle interleave with the other's on the same CUs.  A workgroup only ever waits for lower-indexed workgroups of its
+    OWN launch, which were dispatched before it: progress does not depend on who else is resident.  No wait may time
+    out (`dataflow_fallbacks`, `solve_timeouts` stay zero) and every solve meets the residual bound."""
+    import threading
+
+    from bench import make_problem
+    from sleqp_amd.fact import HipFact
+    from sleqp_amd.sparse import SleqpMat
+
+    out = [None, None]
+
+    def worker(t):
+        try:
+            J, N, cp, ri, vx, b = make_problem("banded_n1e5_m5e4", t)
+            K = synth.kkt_full_matrix(N, cp, ri, vx)
+            f = HipFact(device=0)
+            worst = 0.0
+            for rep in range(6):
+                f.set_matrix(SleqpMat(N, N, cp, ri, vx))
+                for _ in range(4):
+                    f.solve(b)
+                z = f.solution_raw(0, N)
+                worst = max(worst, scaled_residual(K, z, b))
+            out[t] = (worst, f.info("dataflow_fallbacks"), f.info("solve_timeouts"))
+            f.free()
+        except Exception as e:  # noqa: BLE001
+            out[t] = e
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for r in out:
+        assert not isinstance(r, Exception), r
+        assert r[0] <= RESID_TOL and r[1] == 0 and r[2] == 0, r
