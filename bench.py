@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
-PROFILE_TAG = "r5"
+PROFILE_TAG = "r6"
 
 
 def make_problem(workload: str, seed: int):

@@ -3,7 +3,7 @@
 # summaries are then copied into profiles/ (tracked) by scripts/collect_profiles.py.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
