@@ -50,7 +50,7 @@ def build():
         ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n", None, "\n  TRS(3);\n")])
     s = patch(s, [("  const int par = *epoch & 1;  // constant while anybody reads it", "  TRS(0);\n")])
     # the top block as one product (dev_top_one): entry | prefetch issued | lists in LDS | gathered | posted
-    s = segment(s, "__device__ __forceinline__ void dev_top_one(", "// Z = X_T^T D_T^-1 X_T from the dense X_T", [
+    s = segment(s, "__device__ __forceinline__ void dev_top_one(", "__global__ __launch_bounds__(FB) void k_top_dinv(", [
         ("  if (tid < nr) {\n    sent_f64(ysol_prev + B.tpos[I.r0 + tid]);", "  TRS(1);\n"),
         ("  constexpr int GK = 6;", "  TRS(4);\n"),
         ("  __syncthreads();\n  double acc = 0.0;", None, "\n  TRS(2);"),
