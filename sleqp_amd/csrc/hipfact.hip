@@ -26,6 +26,9 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
