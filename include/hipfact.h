@@ -427,6 +427,11 @@ int hipfact_get_info(const hipfact_handle* h, const char* name, double* value);
  * state to the host ("L", "SPf", "SPb", "sitems", "y", "xhat", "ysol", "uvec", "dscale"). */
 int hipfact_debug_copy(hipfact_handle* h, const char* name, void* out, size_t bytes);
 
+/* Host-only self-test of the worker pool behind the row dictionary's passes over K (no GPU needed): `callers` threads
+ * run `rounds` threaded regions each, concurrently; returns the number of regions that did not cover their range exactly
+ * once (0 = sound). */
+int hipfact_debug_pool_selftest(int callers, int rounds);
+
 /* ---- host-only symbolic plan (no GPU needed; used by the tests) ---------- */
 
 typedef struct hipfact_plan hipfact_plan;

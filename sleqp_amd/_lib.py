@@ -30,7 +30,7 @@ SYMBOLS = [
     "hipfact_solve_device", "hipfact_solution_device", "hipfact_synchronize", "hipfact_check", "hipfact_stream",
     "hipfact_assemble_kkt", "hipfact_reduced_matrix", "hipfact_spmat_create", "hipfact_spmat_update_values", "hipfact_spmat_free",
     "hipfact_spmat_mult_vec", "hipfact_spmat_mult_vec_trans", "hipfact_spmat_mult_vec_sym",
-    "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_tr_solve", "hipfact_tr_solve_ex", "hipfact_tridiag_tr", "hipfact_set_option", "hipfact_get_info", "hipfact_debug_copy", "hipfact_plan_create",
+    "hipfact_spmat_mult_device", "hipfact_steihaug_solve", "hipfact_tr_solve", "hipfact_tr_solve_ex", "hipfact_tridiag_tr", "hipfact_set_option", "hipfact_get_info", "hipfact_debug_copy", "hipfact_debug_pool_selftest", "hipfact_plan_create",
     "hipfact_plan_free", "hipfact_plan_error", "hipfact_plan_array", "hipfact_plan_scalar",
 ]
 
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     lib.hipfact_tridiag_tr.argtypes = [ci, vp, vp, cd, cd, vp, C.POINTER(cd)]
     lib.hipfact_set_option.argtypes = [vp, C.c_char_p, cd]
     lib.hipfact_debug_copy.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    lib.hipfact_debug_pool_selftest.argtypes = [ci, ci]
     lib.hipfact_get_info.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
     lib.hipfact_plan_create.argtypes = [ci, vp, vp, vp, C.POINTER(vp)]
     lib.hipfact_plan_free.argtypes = [C.POINTER(vp)]

@@ -347,3 +347,15 @@ def test_active_bounds_do_not_deepen_the_tree(hipfact_lib):
     b = np.random.default_rng(5).standard_normal(N)
     z = EmulFactor(P, vx).solve(b)
     assert np.abs(K @ z - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+
+
+def test_worker_pool_of_the_row_dictionary_under_concurrent_callers():
+    """The passes over K of hipfact_set_matrix run on a process-wide worker pool (vtable_superset.inc).  Two handles on
+    two threads (thread_test.c:77-110; tests/test_gpu_parity.py::test_two_full_size_handles_share_one_gpu) enter it at
+    the same time: one region runs on the workers, the other alone on its caller's thread - every region covers its range
+    exactly once, and nobody waits for ever (a first version shared the job slot between callers and hung)."""
+    import sleqp_amd
+
+    lib = sleqp_amd.load()
+    assert lib.hipfact_debug_pool_selftest(1, 50) == 0
+    assert lib.hipfact_debug_pool_selftest(8, 200) == 0
