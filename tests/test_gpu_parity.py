@@ -1845,6 +1845,45 @@ def test_dataflow_timeout_falls_back_to_per_level_launches(fact, shape):
     f2.solve(2.0 * b)
     assert rel_err(f2.solution_raw(0, N), 2.0 * good) <= 1e-11
     f2.free()
+    # (3) in a device-resident loop (bench.py's unit: refactor_device + solve_device, nothing synchronises in between):
+    # hipfact_check finds the timeout - it may be the unchecked factorisation's - and repeats factorisation and solve on
+    # the per-level path, into the caller's device buffer (two ranks sharing one GPU have been seen to time out: the
+    # bench must not die of it)
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")  # (device buffers from the HIP runtime the library is linked against)
+
+    def to_device(a):
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        return ptr
+
+    def to_host(ptr, count):
+        out = np.empty(count)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    f3 = HipFact(device=0)
+    f3.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    d_vals = to_device(np.ascontiguousarray(kd, dtype=np.float64))
+    d_b = to_device(np.ascontiguousarray(b))
+    d_z = to_device(np.zeros(N))
+    for _ in range(2):
+        f3.refactor_device(d_vals.value)
+        f3.solve_device(d_b.value, d_z.value)
+    f3.set_option("debug_fake_timeout", 1)
+    f3.check()
+    assert f3.info("no_dataflow") == 1 and f3.info("dataflow_fallbacks") == 1
+    z3 = to_host(d_z, N)
+    assert rel_err(z3, good) <= 1e-11 and scaled_residual(K, z3, b) <= RESID_TOL
+    f3.refactor_device(d_vals.value)
+    f3.solve_device(d_b.value, d_z.value)
+    f3.check()
+    assert rel_err(to_host(d_z, N), good) <= 1e-11
+    f3.free()
+    for ptr in (d_vals, d_b, d_z):
+        hip.hipFree(ptr)
 
 
 def test_pull_with_more_children_than_one_descriptor_block(fact):
