@@ -202,7 +202,8 @@ constexpr int TOP_REL_CAP = 2048;   // ints of children's relative indices stage
 constexpr int TOP_L21_CAP = 16384;  // doubles of L21 (forward) / inv(L11) (backward) staged in LDS
 
 // info words written by the factorisation kernels
-enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_TIMEOUT = 2, INFO_WORDS = 4 };
+// (INFO_TIMEOUT_WG: 2^30 - the lowest workgroup index of a solve launch whose wait timed out, 0 if none)
+enum { INFO_ZERO_PIVOT = 0, INFO_NEG_PIVOT = 1, INFO_TIMEOUT = 2, INFO_TIMEOUT_WG = 3, INFO_WORDS = 4 };
 // ... followed by two 64-bit words: pivot minimum (bit-inverted) and maximum (k_pivot_minmax)
 constexpr int INFO_BYTES = INFO_WORDS * 4 + 16;
 
