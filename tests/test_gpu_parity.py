@@ -1884,6 +1884,42 @@ def test_dataflow_timeout_falls_back_to_per_level_launches(fact, shape):
     f3.free()
     for ptr in (d_vals, d_b, d_z):
         hip.hipFree(ptr)
+    # (4) "for good" ends: after HIPFACT_DATAFLOW_RETRY more factorisations (256 by default, doubled with every
+    # fallback) the handle tries the single-launch kernels again - what ended the wait is another tenant of the GPU,
+    # and that one need not stay.  The exchange slots the per-level solves used as plain memory are sentinels again.
+    import os
+
+    os.environ["HIPFACT_DATAFLOW_RETRY"] = "3"
+    try:
+        f4 = HipFact(device=0)
+    finally:
+        del os.environ["HIPFACT_DATAFLOW_RETRY"]
+    f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    f4.set_option("debug_fake_timeout", 1)
+    f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert f4.info("no_dataflow") == 1 and f4.info("dataflow_rearmed") == 0
+    seen = []
+    for rep in range(5):
+        f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+        seen.append(int(f4.info("no_dataflow")))
+        for scale in (1.0, -0.5):
+            f4.solve(scale * b)
+            z4 = f4.solution_raw(0, N)
+            assert rel_err(z4, scale * good) <= 1e-11 and scaled_residual(K, z4, scale * b) <= RESID_TOL
+    assert seen[0] == 1 and seen[-1] == 0 and f4.info("dataflow_rearmed") == 1 and f4.info("dataflow_fallbacks") == 1, seen
+    # (the second fallback doubles the distance)
+    f4.set_option("debug_fake_timeout", 1)
+    f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert f4.info("no_dataflow") == 1 and f4.info("dataflow_fallbacks") == 2
+    for rep in range(4):
+        f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    assert f4.info("no_dataflow") == 1
+    for rep in range(4):
+        f4.set_matrix(SleqpMat(N, N, kc, kr, kd))
+    f4.solve(b)
+    assert f4.info("no_dataflow") == 0 and f4.info("dataflow_rearmed") == 2
+    assert rel_err(f4.solution_raw(0, N), good) <= 1e-11
+    f4.free()
 
 
 def test_pull_with_more_children_than_one_descriptor_block(fact):
