@@ -354,7 +354,12 @@ bool amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm, std::ve
     if (p != s + 1) continue;
     RawSuper& b = sn[p];
     const int wm = a.w + b.w;
-    if (wm > prm.wmax) continue;
+    // (a parent that is wider than one front already - a dense leaf clique, cut into a chain by split_wide - takes a
+    // small child in as long as the chain gets no longer: the child would be one more LEVEL under it)
+    auto parts = [&](int w) { return (w + prm.wmax - 1) / prm.wmax; };
+    // ... and a link of a chain (an only child) joins its parent whatever the width: split_wide cuts the merged
+    // columns into the fewest fronts that fit, never more than the two had apart
+    if (wm > prm.wmax && nch[p] != 1 && (b.w <= prm.wmax || parts(wm) > parts(b.w))) continue;
     if (prm.max_children > 0 && nch[p] - 1 + nch[s] > std::max(prm.max_children, nch[p])) continue;
     const int64_t ua = (int64_t)a.rows.size() - a.w;
     const int64_t rb = (int64_t)b.rows.size();
@@ -370,6 +375,8 @@ bool amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm, std::ve
       ok = frac < prm.relax_mid;
     else
       ok = frac < prm.relax_big;
+    // (a handful of columns never justify a tree level of their own: whatever zeros the parent has collected already)
+    ok = ok || (a.w <= 8 && (double)((int64_t)a.w * (rb - ua)) < 0.06 * (double)tot);
     if (!ok) continue;
     std::vector<int> rows;
     rows.reserve(a.w + b.rows.size());
@@ -408,13 +415,15 @@ bool amalgamate(std::vector<RawSuper>& sn, int m, const PlanParams& prm, std::ve
       if (p == s + 1 || p < 0) continue;
       RawSuper& b = sn[p];
       const int wm = a.w + b.w;
-      if (wm > prm.wmax) continue;
+      auto parts = [&](int w) { return (w + prm.wmax - 1) / prm.wmax; };
+      if (wm > prm.wmax && (b.w <= prm.wmax || parts(wm) > parts(b.w))) continue;
       const int64_t ua = (int64_t)a.rows.size() - a.w;
       const int64_t rb = (int64_t)b.rows.size();
       const int64_t zeros = a.zeros + b.zeros + (int64_t)a.w * (rb - ua);
       const int64_t tot = trapezoid(wm, a.w + rb);
       const double frac = (double)zeros / (double)tot;
-      const bool ok = wm <= 4 || frac < (wm <= 32 ? prm.relax_small : wm <= 64 ? prm.relax_mid : prm.relax_big);
+      const bool ok = wm <= 4 || frac < (wm <= 32 ? prm.relax_small : wm <= 64 ? prm.relax_mid : prm.relax_big) ||
+                      (a.w <= 8 && (double)((int64_t)a.w * (rb - ua)) < 0.06 * (double)tot);
       if (!ok) continue;
       // b keeps its own numbering for now: rows = [adopted columns | own rows] is formed by the renumbering below
       adopted[p].push_back(s);
@@ -472,32 +481,27 @@ void split_wide(std::vector<RawSuper>& sn, int wmax) {
       out.push_back(std::move(s));
       continue;
     }
-    // segments between the joins, combined greedily up to the cap; a segment wider than the cap
-    // (a genuine chain, e.g. a dense Schur complement) is cut evenly
+    // The fewest parts that fit the cap (every part of the chain is a tree LEVEL on the device), cut evenly; a cut
+    // moves to a join of the merged fronts when one lies within an eighth of a part of the even position (in front of
+    // a join the columns have the shorter structure they had before the merge) and every part still fits.
     std::vector<int> cuts;  // first columns of the parts
     {
-      std::vector<int> bounds(1, 0);
+      const int np = (s.w + wmax - 1) / wmax;
+      std::vector<int> joins;
       for (int q : s.joins)
-        if (q > bounds.back() && q < s.w) bounds.push_back(q);
-      bounds.push_back(s.w);
-      int start = 0;
+        if (q > 0 && q < s.w) joins.push_back(q);
+      std::sort(joins.begin(), joins.end());
       cuts.push_back(0);
-      for (size_t t = 1; t < bounds.size(); ++t) {
-        const int seg0 = bounds[t - 1], seg1 = bounds[t];
-        if (seg1 - start <= wmax) continue;  // the segment still fits the open part
-        if (seg0 > start) {                  // close the open part in front of the segment
-          cuts.push_back(seg0);
-          start = seg0;
-        }
-        if (seg1 - start > wmax) {  // the segment alone is too wide: even pieces
-          const int len = seg1 - start, np = (len + wmax - 1) / wmax;
-          int done = 0;
-          for (int p = 0; p + 1 < np; ++p) {
-            done += (len - done) / (np - p);
-            cuts.push_back(start + done);
-          }
-          start = cuts.back();
-        }
+      for (int p = 1; p < np; ++p) {
+        const int ideal = (int)(((long long)p * s.w + np / 2) / np);
+        const int lo = std::max(cuts.back() + 1, s.w - (np - p) * wmax), hi = std::min(cuts.back() + wmax, s.w - (np - p));
+        int cut = std::min(std::max(ideal, lo), hi);
+        const int tol = std::max(1, s.w / (8 * np));
+        int best = -1;
+        for (int q : joins)
+          if (q >= lo && q <= hi && std::abs(q - ideal) <= tol && (best < 0 || std::abs(q - ideal) < std::abs(best - ideal))) best = q;
+        if (best >= 0) cut = best;
+        cuts.push_back(cut);
       }
     }
     cuts.push_back(s.w);

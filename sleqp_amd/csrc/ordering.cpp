@@ -707,11 +707,43 @@ struct NDState {
         const int after = k - before - sz;
         const int small = std::min(before, after);
         if (small < prm.balance * k) continue;
-        const double cost = (double)sz * (1.0 + 0.5 * std::abs(before - after) / (double)k);
+        const double cost = (double)sz * (1.0 + prm.balance_weight * std::abs(before - after) / (double)k);
         if (cost < best_cost) {
           best_cost = cost;
           best_l = l;
         }
+      }
+      // The device pays for every LEVEL of the tree (a dependent pivot block, ~25 us) before it pays for fill: among
+      // the cuts within depth_tol of the cheapest, take the one under which the deeper side needs the fewest further
+      // dissections - estimated with separators of this cut's size and leaves of one front each: a subgraph of k
+      // vertices needs d more levels when k <= cap(d), cap(0) = leaf_size, cap(d) = 2 cap(d - 1) + sz.  (A band of
+      // 5e4 rows with 84-row separators fits 256 single-front leaves under 8 levels of separators - if no cut
+      // leaves more than cap(d - 1) on one side; the cheapest cut alone gave 11 levels, two of them from sides that
+      // missed their capacity by a few per cent.)
+      if (best_l >= 0 && prm.depth_tol > 0.0) {
+        auto need = [&](int kk, int sz) {
+          int d = 0;
+          for (long long cap = prm.leaf_size; cap < kk && d < 40; ++d) cap = 2 * cap + sz;
+          return d;
+        };
+        int best_d = 1 << 30;
+        double best_c2 = 1e300;
+        int pick = best_l;
+        for (int l = 1; l + 1 < nlev; ++l) {
+          const int before = lev_ptr[l];
+          const int sz = lev_ptr[l + 1] - lev_ptr[l];
+          const int after = k - before - sz;
+          if (std::min(before, after) < prm.balance * k) continue;
+          const double cost = (double)sz * (1.0 + prm.balance_weight * std::abs(before - after) / (double)k);
+          if (cost > (1.0 + prm.depth_tol) * best_cost) continue;
+          const int d = std::max(need(before, sz), need(after, sz));
+          if (d < best_d || (d == best_d && cost < best_c2)) {
+            best_d = d;
+            best_c2 = cost;
+            pick = l;
+          }
+        }
+        best_l = pick;
       }
       if (best_l >= 0) {
         left.assign(order.begin(), order.begin() + lev_ptr[best_l]);
