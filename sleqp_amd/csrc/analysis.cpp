@@ -854,6 +854,8 @@ bool build_plan(int N, const int* Kp, const int* Ki, const double* Kx, const Pla
       if (const char* e = getenv("HIPFACT_ND_SMALL_SEP_FRAC")) nd.small_sep_frac = atof(e);
       if (const char* e = getenv("HIPFACT_ND_REFINE")) nd.refine = atoi(e) != 0;
       if (const char* e = getenv("HIPFACT_ND_BALANCE")) nd.balance = atof(e);
+      if (const char* e = getenv("HIPFACT_ND_BALANCE_W")) nd.balance_weight = atof(e);
+      if (const char* e = getenv("HIPFACT_ND_DEPTH_TOL")) nd.depth_tol = atof(e);
       nd_order(gg, nd, pp);
     }
   };

@@ -31,7 +31,7 @@ struct NDParams {
   int small_k = 2048;
   double balance = 0.15;      // smaller side must hold at least this fraction
   double balance_weight = 0.5; // cost of a cut: separator size x (1 + balance_weight |left - right| / k)
-  double depth_tol = 0.15;     // cuts within this of the cheapest compete on the estimated depth of the subtree (0 = off)
+  double depth_tol = 0.4;      // cuts within this of the cheapest compete on the estimated depth of the subtree (0 = off; 0.15 / 0.25 / 0.4 / 0.6: 22 / 21 / 18 / 18 levels on the 2-D grid of the bench, 54 / 48 / 48 / 47 on the 3-D one, at -19 .. -24 % / -15 .. -20 % of the flops of 0)
   // FM-refined edge bisection + minimum vertex cover as a second separator candidate.  Off by
   // default: on the band-like benchmark graphs it shrinks the separators by ~3 % but the resulting
   // trees factor 1-5 % slower (HIPFACT_ND_REFINE=1 to try it on other graph classes).
