@@ -48,7 +48,7 @@ def build():
         ("  const int myrow = (tid >= top && tid < ro) ? rows[T.rowoff + w + a0 + (tid - top)] : -1;", "  TRS(1);\n"),
         ("    if (tid >= top && tid < ro) sent_f64_agent(uvec + T.uoff + a0 + (tid - top));\n  }\n  __syncthreads();", None, "\n  TRS(2);"),
         ("      y[T.c0 + tid] = s2;\n      post_f64(ysol + T.c0 + tid, s2);\n    }\n  }\n", None, "\n  TRS(3);\n")])
-    s = patch(s, [("  const int par = *epoch & 1;  // constant while anybody reads it", "  TRS(0);\n")])
+    s = patch(s, [("  const int par = *epoch & 1;\n  if ((int)blockIdx.x > nall) {", "  TRS(0);\n")])
     # the top block as one product (dev_top_one): entry | prefetch issued | lists in LDS | gathered | posted
     s = segment(s, "__device__ __forceinline__ void dev_top_one(", "__global__ __launch_bounds__(FB) void k_top_dinv(", [
         ("  if (tid < nr) {\n    sent_f64(ysol_prev + B.tpos[I.r0 + tid]);", "  TRS(1);\n"),
