@@ -201,6 +201,39 @@ def test_config4_scale_statistics(hipfact_lib):
     _structure_invariants(P)
 
 
+def test_trees_are_as_short_as_the_fronts_allow(hipfact_lib, monkeypatch):
+    """Round 6 ("shorter trees"): a tree level is ~26 us of dependent pivot block on the device, so the
+    analysis spends fill on depth.  The band of BASELINE's config 4: 8 levels of separators over leaves of one or two
+    fronts (11 levels / 595 fronts before), no chain of more fronts than its columns need, nearly the same flops.  A 2-D
+    and a 3-D grid: fewer levels AND fewer flops than the cheapest-cut dissection (`HIPFACT_ND_DEPTH_TOL=0`)."""
+    J = synth.banded_jacobian(100000, 50000, 20, 200, 0)
+    P = Plan(hipfact_lib, *synth.kkt_lower_from_jacobian(J))
+    assert P.nlevels <= 10 and P.nsuper <= 580 and P.flops <= 2.32e9, (P.nlevels, P.nsuper, P.flops)
+    w = np.diff(P.sn_c0)
+    nch = np.diff(P.child_ptr)
+    # chains (runs of only children): never more fronts than ceil(columns / 128) + 1
+    for s in range(P.nsuper):
+        if nch[s] != 0:
+            continue
+        cols, links, t = int(w[s]), 1, s
+        while P.sn_parent[t] >= 0 and nch[P.sn_parent[t]] == 1:
+            t = P.sn_parent[t]
+            cols += int(w[t])
+            links += 1
+        assert links <= (cols + 127) // 128 + 1, (s, links, cols)
+    # tiny fronts hang under full parents only (a handful of columns never keep a level of their own otherwise)
+    for s in np.flatnonzero((w <= 8) & (P.sn_parent >= 0)):
+        assert w[s] + w[P.sn_parent[s]] > 128 or nch[P.sn_parent[s]] > 1 or P.sn_r[s] - w[s] < 0.5 * P.sn_r[P.sn_parent[s]], s
+    for make, lv, fl in ((lambda: synth.grid2d_jacobian(96, 0), 0, 0), (lambda: synth.grid3d_jacobian(20, 0), 0, 0)):
+        K = synth.kkt_lower_from_jacobian(make())
+        new = Plan(hipfact_lib, *K)
+        monkeypatch.setenv("HIPFACT_ND_DEPTH_TOL", "0")
+        old = Plan(hipfact_lib, *K)
+        monkeypatch.delenv("HIPFACT_ND_DEPTH_TOL")
+        assert new.nlevels <= old.nlevels and new.flops <= 1.02 * old.flops, (new.nlevels, old.nlevels, new.flops, old.flops)
+        _structure_invariants(new)
+
+
 def _late_case(case):
     n, m = 600, 300
     J = synth.banded_jacobian(n, m, 10, 70, 4)
